@@ -1,0 +1,189 @@
+/* mia.h — C ABI of libmia_hip.so, the MI355X (gfx950) spectral front-end.
+ *
+ * Drop-in boundary for the reference's optional native extension
+ * `mlx_audio.primitives._ext` (nanobind module, python/csrc/bindings.cpp:13-598)
+ * and for the third-party array ops the reference's Python path calls
+ * (mx.fft.rfft / irfft / matmul).  Citations below are relative to the
+ * reference checkout.
+ *
+ * Conventions
+ *   - plain C types only; device buffers are raw pointers into HIP device
+ *     memory owned by the caller (PyTorch-ROCm tensors on the Python side);
+ *   - all device work is enqueued on `stream` (a hipStream_t passed as void*);
+ *     no function synchronises, allocates or frees device memory except
+ *     mia_plan_create / mia_plan_destroy;
+ *   - inputs and outputs are contiguous float32 / interleaved complex64 unless
+ *     strides are passed;
+ *   - every function returns MIA_OK or a negative MIA_ERR_*; the message for
+ *     the calling thread is available from mia_last_error().
+ */
+#ifndef MIA_H_
+#define MIA_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MIA_OK 0
+#define MIA_ERR_INVALID (-1)     /* bad argument (maps to ValueError)          */
+#define MIA_ERR_UNSUPPORTED (-2) /* e.g. n_fft without a compiled FFT plan     */
+#define MIA_ERR_HIP (-3)         /* HIP runtime failure (maps to RuntimeError) */
+
+#define MIA_PAD_CONSTANT 0
+#define MIA_PAD_EDGE 1
+#define MIA_PAD_REFLECT 2
+
+#define MIA_EPI_NONE 0        /* mel power as is                                */
+#define MIA_EPI_WHISPER 1     /* log10(max(.,1e-10)), max-8 clamp, (.+4)/4      */
+#define MIA_EPI_DB 2          /* coef*log10(max(.,amin)/max(ref,amin)), top_db  */
+
+typedef struct mia_plan mia_plan;
+
+const char* mia_last_error(void);
+int mia_version(void);
+
+/* ---- host-side table builders (float64 arithmetic, float32 results) -------- */
+
+/* Window taps.  Replaces _ext.generate_window (bindings.cpp:107-132,
+ * csrc/primitives/windows.cpp:179-228); follows the NumPy fallback
+ * primitives/windows.py:19-122,166-186 (no symmetrisation step).  `type` is one
+ * of hann|hanning|hamming|blackman|bartlett|triangular|rectangular|boxcar|ones.
+ * periodic != 0: length+1 symmetric points without the last. */
+int mia_generate_window(const char* type, int length, int periodic, float* out);
+
+/* Replace _ext.hz_to_mel / _ext.mel_to_hz (bindings.cpp:135-183); formulas of
+ * primitives/mel.py:42-104 (Slaney or HTK), float64 in and out. */
+int mia_hz_to_mel(const double* hz, int n, int htk, double* out);
+int mia_mel_to_hz(const double* mels, int n, int htk, double* out);
+
+/* Replaces _ext.mel_filterbank (bindings.cpp:185-223); follows the builder the
+ * reference actually calls, primitives/mel.py:111-179: eps-regularised slopes,
+ * cast to float32, then slaney scale.  norm: 0 = None, 1 = "slaney".
+ * out: n_mels x (n_fft/2+1) row-major. */
+int mia_mel_filterbank(int sr, int n_fft, int n_mels, double fmin, double fmax,
+                       int htk, int norm, float* out);
+
+/* Replaces _ext.get_dct_matrix (bindings.cpp:315-340); float64 basis cast to
+ * float32 as primitives/mfcc.py:23-66.  out: n_out x n_in row-major. */
+int mia_dct_matrix(int n_out, int n_in, int ortho, float* out);
+
+/* ---- plans ------------------------------------------------------------------ */
+
+typedef struct mia_plan_desc {
+  int n_fft;
+  int hop_length;
+  int center;            /* 0/1 */
+  int pad_mode;          /* MIA_PAD_*  */
+  const float* window;   /* host, n_fft taps (already centre-padded)            */
+  int n_mels;            /* 0: no mel stage                                     */
+  const float* mel_basis;/* host, n_mels x (n_fft/2+1)                          */
+  float power;           /* exponent applied to |X| before the projection       */
+  int n_mfcc;            /* 0: no DCT stage                                     */
+  const float* dct_basis;/* host, n_mfcc x n_mels                               */
+  const float* lifter;   /* host, n_mfcc multipliers or NULL                    */
+} mia_plan_desc;
+
+/* Uploads window, twiddles, the band form of the filterbank and the DCT basis
+ * to the current device.  Stands in for the reference's table caches
+ * (primitives/stft.py:27-106, mel.py:107-120,239-253, mfcc.py:19-66,
+ * csrc/primitives/dct.cpp:19-42). */
+int mia_plan_create(const mia_plan_desc* desc, mia_plan** out);
+int mia_plan_destroy(mia_plan* plan);
+/* 1 + (T + 2*pad - n_fft) / hop, or a negative error if the signal is too short
+ * (primitives/_frame_impl.py:116-122). */
+int64_t mia_plan_num_frames(const mia_plan* plan, int64_t T);
+int mia_fft_size_supported(int n_fft);
+
+/* ---- the hot path ------------------------------------------------------------ */
+
+/* Fused pad + frame + window + real FFT.  Replaces the compiled core
+ * primitives/stft.py:118-130 (incl. _ext.pad_signal / _ext.frame_signal and
+ * mx.fft.rfft).  y: (B, T) float32.  out: (B, F, n_fft/2+1) complex64 — the
+ * physical layout of the reference's result before its lazy transpose
+ * (stft.py:213-216).  Every value is multiplied by `scale`. */
+int mia_stft(const mia_plan* plan, const float* y, int64_t B, int64_t T,
+             float scale, void* out, void* stream);
+
+/* Inverse real FFT of every frame.  Replaces mx.fft.irfft at
+ * primitives/stft.py:295.  spec is addressed as
+ * spec[b*stride_b + k*stride_bin + f*stride_frame] (complex elements), so both
+ * the (B, bins, F) contiguous layout and the transposed view that mia_stft
+ * produces are read in place.  frames: (B, F, n_fft) float32. */
+int mia_irfft_frames(const mia_plan* plan, const void* spec, int64_t B, int64_t F,
+                     int64_t stride_b, int64_t stride_bin, int64_t stride_frame,
+                     float* frames, void* stream);
+
+/* Gather-formulated overlap-add with window-sum normalisation.  Replaces
+ * _ext.overlap_add (bindings.cpp:17-48, csrc/primitives/overlap_add.cpp:195-233)
+ * and the inline kernel primitives/stft.py:548-596:
+ *   out[b,i] = sum_f w[i-f*hop] * frames[b,f,i-f*hop] / max(sum_f w[i-f*hop]^2, 1e-8)
+ * frames: (B, F, n_fft); window: device, n_fft; out: (B, out_len).  Every
+ * value is multiplied by `scale` after the division. */
+int mia_overlap_add(const float* frames, const float* window, int64_t B, int64_t F,
+                    int n_fft, int hop, int64_t out_len, float scale, float* out,
+                    void* stream);
+
+/* Inverse STFT = mia_irfft_frames + mia_overlap_add (primitives/stft.py:292-312).
+ * `workspace` must hold mia_istft_workspace_bytes() bytes of device memory. */
+size_t mia_istft_workspace_bytes(const mia_plan* plan, int64_t B, int64_t F);
+int mia_istft(const mia_plan* plan, const void* spec, int64_t B, int64_t F,
+              int64_t stride_b, int64_t stride_bin, int64_t stride_frame,
+              int64_t out_len, float scale, float* out, void* workspace,
+              size_t workspace_bytes, void* stream);
+
+/* Fused STFT -> |X|^power -> mel projection -> optional log epilogue.
+ * Replaces primitives/mel.py:345-373 (+ :265-276) and, by epilogue,
+ * models/whisper/inference.py:111-113 or primitives/convert.py:42-57.
+ * out: (B, n_mels, F) float32, frames contiguous.
+ *   MIA_EPI_NONE   : mel power.
+ *   MIA_EPI_WHISPER: (max(log10(max(mel,1e-10)), gmax-8)+4)/4.
+ *   MIA_EPI_DB     : max(coef*log10(max(mel,amin)/max(ref,amin)), gmax-top_db);
+ *                    top_db < 0 means "no clamp".
+ * gmax is the maximum over each clip (per_clip != 0) or over the whole batch
+ * (per_clip == 0, what the reference computes for the array it is given).
+ * `workspace` must hold mia_mel_workspace_bytes() bytes. */
+size_t mia_mel_workspace_bytes(const mia_plan* plan, int64_t B, int64_t T);
+int mia_melspectrogram(const mia_plan* plan, const float* y, int64_t B, int64_t T,
+                       int epilogue, float ref, float amin, float coef, float top_db,
+                       int per_clip, float* out, void* workspace,
+                       size_t workspace_bytes, void* stream);
+
+/* MFCC from waveform: the chain above with MIA_EPI_DB(ref=1, amin=1e-10,
+ * top_db=80) followed by DCT-II along the mel axis and the lifter
+ * (primitives/mfcc.py:226-281).  out: (B, n_mfcc, F). */
+size_t mia_mfcc_workspace_bytes(const mia_plan* plan, int64_t B, int64_t T);
+int mia_mfcc(const mia_plan* plan, const float* y, int64_t B, int64_t T, float top_db,
+             int per_clip, float* out, void* workspace, size_t workspace_bytes,
+             void* stream);
+
+/* ---- stand-alone ops of the reference extension ------------------------------- */
+
+/* _ext.pad_signal (bindings.cpp:78-104, csrc/primitives/pad_signal.cpp:133-162):
+ * (B, T) -> (B, T + 2*pad). */
+int mia_pad_signal(const float* x, int64_t B, int64_t T, int64_t pad, int mode,
+                   float* out, void* stream);
+/* _ext.frame_signal (bindings.cpp:50-76, csrc/primitives/frame_signal.cpp:119-155):
+ * (B, T) -> (B, 1 + (T - L)/hop, L). */
+int mia_frame_signal(const float* x, int64_t B, int64_t T, int frame_length, int hop,
+                     float* out, void* stream);
+/* primitives/convert.py:14-57 on an existing array: x viewed as (B, n) —
+ * out = coef*log10(max(x,amin)/max(ref,amin)), clamped to (max - top_db) per row
+ * (per_clip) or over everything; top_db < 0: no clamp.  workspace: >= 4*(B+1) bytes. */
+int mia_to_db(const float* x, int64_t B, int64_t n, float ref, float amin, float coef,
+              float top_db, int per_clip, float* out, void* workspace, void* stream);
+/* _ext.dct (bindings.cpp:342-370, csrc/primitives/dct.cpp:103-159) along the
+ * middle axis of x viewed as (outer, n_in, inner):
+ *   out[o,k,i] = sum_n basis[k,n] * x[o,n,i];  basis: device, n_out x n_in. */
+int mia_dct2(const float* x, int64_t outer, int n_in, int64_t inner, const float* basis,
+             int n_out, float* out, void* stream);
+/* |z| and atan2(im, re) of n complex64 values (primitives/stft.py:347-379). */
+int mia_magnitude(const void* z, int64_t n, float* out, void* stream);
+int mia_phase(const void* z, int64_t n, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIA_H_ */

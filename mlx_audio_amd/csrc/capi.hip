@@ -1,0 +1,580 @@
+// extern "C" surface of libmia_hip.so: error reporting, host-side table
+// builders, plan management and the launch wrappers.
+#include <cmath>
+#include <cstring>
+#include <mutex>
+
+#include "mia_internal.h"
+
+namespace mia {
+
+static thread_local std::string g_last_error;
+
+void set_error(const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+}
+
+int launch_overlap_add(const float*, const float*, long long, long long, int, int, long long,
+                       float, float*, hipStream_t);
+int launch_pad(const float*, long long, long long, long long, int, float*, hipStream_t);
+int launch_frame(const float*, long long, long long, long long, int, int, float*, hipStream_t);
+int launch_to_db(const float*, long long, long long, float, float, float, float, int, float*,
+                 int*, hipStream_t);
+int launch_floor_tiles(float*, long long, int, long long, int, int, int*, const float*, int,
+                       float, int, hipStream_t);
+int launch_dct2(const float*, long long, int, long long, const float*, int, float*, const int*,
+                long long, float, hipStream_t);
+int launch_magnitude(const float2*, long long, float*, hipStream_t);
+int launch_reduce_keys(int*, long long, hipStream_t);
+int launch_phase(const float2*, long long, float*, hipStream_t);
+
+// --------------------------- table builders --------------------------------
+
+constexpr double kSlaneyFMin = 0.0;
+constexpr double kSlaneyFSp = 200.0 / 3;
+constexpr double kSlaneyMinLogHz = 1000.0;
+static const double kSlaneyLogstep = std::log(6.4) / 27.0;
+constexpr double kSlaneyMinLogMel = (kSlaneyMinLogHz - kSlaneyFMin) / kSlaneyFSp;
+constexpr double kHtkFactor = 2595.0, kHtkBase = 700.0;
+constexpr double kFilterbankEps = 1e-10;
+
+static double hz_to_mel1(double f, bool htk) {
+  if (htk) return kHtkFactor * std::log10(1.0 + f / kHtkBase);
+  if (f < kSlaneyMinLogHz) return (f - kSlaneyFMin) / kSlaneyFSp;
+  return kSlaneyMinLogMel + std::log(f / kSlaneyMinLogHz) / kSlaneyLogstep;
+}
+static double mel_to_hz1(double m, bool htk) {
+  if (htk) return kHtkBase * (std::pow(10.0, m / kHtkFactor) - 1.0);
+  if (m < kSlaneyMinLogMel) return kSlaneyFMin + kSlaneyFSp * m;
+  return kSlaneyMinLogHz * std::exp(kSlaneyLogstep * (m - kSlaneyMinLogMel));
+}
+
+// numpy.linspace(a, b, n): a + i*step with step = (b-a)/(n-1), last point = b.
+static std::vector<double> linspace(double a, double b, int n) {
+  std::vector<double> v((size_t)n);
+  if (n == 1) {
+    v[0] = a;
+    return v;
+  }
+  const double step = (b - a) / double(n - 1);
+  for (int i = 0; i < n; ++i) v[(size_t)i] = a + double(i) * step;
+  v[(size_t)n - 1] = b;
+  return v;
+}
+
+static int window_kind(const char* type) {
+  static const struct { const char* name; int kind; } names[] = {
+      {"hann", 0}, {"hanning", 0}, {"hamming", 1}, {"blackman", 2}, {"bartlett", 3},
+      {"triangular", 3}, {"rectangular", 4}, {"boxcar", 4}, {"ones", 4}};
+  for (auto& e : names) {
+    if (strcasecmp(type, e.name) == 0) return e.kind;
+  }
+  return -1;
+}
+
+}  // namespace mia
+
+using namespace mia;
+
+extern "C" {
+
+const char* mia_last_error(void) { return g_last_error.c_str(); }
+int mia_version(void) { return 100; }
+
+int mia_generate_window(const char* type, int length, int periodic, float* out) {
+  MIA_REQUIRE(type != nullptr && out != nullptr, "null argument");
+  MIA_REQUIRE(length >= 0, "Window length must be non-negative, got %d", length);
+  const int kind = window_kind(type);
+  MIA_REQUIRE(kind >= 0,
+              "Unknown window type: '%s'. Supported: bartlett, blackman, boxcar, hamming, "
+              "hann, hanning, ones, rectangular, triangular", type);
+  const int n = periodic ? length + 1 : length;
+  for (int k = 0; k < length; ++k) {
+    double w;
+    if (kind == 4 || n <= 1) {
+      w = 1.0;
+    } else if (kind == 3) {
+      w = 1.0 - std::fabs(2.0 * k / double(n - 1) - 1.0);
+    } else {
+      const double d = double(n - 1);
+      if (kind == 0) {
+        w = 0.5 + (-1.0) * 0.5 * std::cos(2.0 * 1 * M_PI * k / d);
+      } else if (kind == 1) {
+        w = 0.54 + (-1.0) * 0.46 * std::cos(2.0 * 1 * M_PI * k / d);
+      } else {
+        w = 0.42 + (-1.0) * 0.5 * std::cos(2.0 * 1 * M_PI * k / d);
+        w = w + 1.0 * 0.08 * std::cos(2.0 * 2 * M_PI * k / d);
+        w = std::fmax(w, 0.0);
+      }
+    }
+    out[k] = (float)w;
+  }
+  return MIA_OK;
+}
+
+int mia_hz_to_mel(const double* hz, int n, int htk, double* out) {
+  MIA_REQUIRE(hz && out && n >= 0, "bad argument");
+  for (int i = 0; i < n; ++i) out[i] = hz_to_mel1(hz[i], htk != 0);
+  return MIA_OK;
+}
+int mia_mel_to_hz(const double* mels, int n, int htk, double* out) {
+  MIA_REQUIRE(mels && out && n >= 0, "bad argument");
+  for (int i = 0; i < n; ++i) out[i] = mel_to_hz1(mels[i], htk != 0);
+  return MIA_OK;
+}
+
+int mia_mel_filterbank(int sr, int n_fft, int n_mels, double fmin, double fmax, int htk,
+                       int norm, float* out) {
+  MIA_REQUIRE(out != nullptr, "null output");
+  MIA_REQUIRE(n_mels > 0, "n_mels must be positive, got %d", n_mels);
+  MIA_REQUIRE(fmin >= 0, "fmin must be non-negative, got %g", fmin);
+  MIA_REQUIRE(fmin < fmax, "fmin (%g) must be less than fmax (%g)", fmin, fmax);
+  MIA_REQUIRE(fmax <= sr / 2.0, "fmax (%g) cannot exceed Nyquist frequency (%g)", fmax,
+              sr / 2.0);
+  MIA_REQUIRE(norm == 0 || norm == 1, "Unknown norm code %d", norm);
+  const int n_freqs = 1 + n_fft / 2;
+  const std::vector<double> fft_freqs = linspace(0.0, sr / 2.0, n_freqs);
+  const std::vector<double> mel_pts =
+      linspace(hz_to_mel1(fmin, htk != 0), hz_to_mel1(fmax, htk != 0), n_mels + 2);
+  std::vector<double> hz((size_t)n_mels + 2);
+  for (int i = 0; i < n_mels + 2; ++i) hz[(size_t)i] = mel_to_hz1(mel_pts[(size_t)i], htk != 0);
+  for (int m = 0; m < n_mels; ++m) {
+    const double lo = hz[(size_t)m], ce = hz[(size_t)m + 1], hi = hz[(size_t)m + 2];
+    const double enorm = 2.0 / (hi - lo);
+    for (int k = 0; k < n_freqs; ++k) {
+      const double f = fft_freqs[(size_t)k];
+      const double lower = (f - lo) / (ce - lo + kFilterbankEps);
+      const double upper = (hi - f) / (hi - ce + kFilterbankEps);
+      float w = (float)std::fmax(0.0, std::fmin(lower, upper));
+      if (norm == 1) w = (float)(double(w) * enorm);  // float32 array *= float64 scale
+      out[(size_t)m * n_freqs + k] = w;
+    }
+  }
+  return MIA_OK;
+}
+
+int mia_dct_matrix(int n_out, int n_in, int ortho, float* out) {
+  MIA_REQUIRE(out != nullptr && n_out > 0 && n_in > 0, "bad argument");
+  for (int k = 0; k < n_out; ++k) {
+    for (int n = 0; n < n_in; ++n) {
+      double v = std::cos(M_PI * double(k) * double(2 * n + 1) / double(2 * n_in));
+      if (ortho) v *= (k == 0) ? 1.0 / std::sqrt(double(n_in)) : std::sqrt(2.0 / double(n_in));
+      out[(size_t)k * n_in + n] = (float)v;
+    }
+  }
+  return MIA_OK;
+}
+
+// ------------------------------- plans -------------------------------------
+
+int mia_fft_size_supported(int n_fft) { return fft_size_supported(n_fft) ? 1 : 0; }
+
+}  // extern "C"
+
+static void plan_free(mia_plan* p) {
+  if (!p) return;
+  (void)hipFree(p->d_window);
+  (void)hipFree(p->d_tw);
+  (void)hipFree(p->d_row_lo);
+  (void)hipFree(p->d_row_len);
+  (void)hipFree(p->d_row_off);
+  (void)hipFree(p->d_wts);
+  (void)hipFree(p->d_dct);
+  delete p;
+}
+
+template <class Tp>
+static int upload(Tp** dst, const std::vector<Tp>& src) {
+  const size_t bytes = sizeof(Tp) * (src.empty() ? 1 : src.size());
+  MIA_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(dst), bytes));
+  if (!src.empty()) {
+    MIA_CHECK_HIP(hipMemcpy(*dst, src.data(), sizeof(Tp) * src.size(), hipMemcpyHostToDevice));
+  }
+  return MIA_OK;
+}
+
+extern "C" {
+
+int mia_plan_create(const mia_plan_desc* d, mia_plan** out) {
+  MIA_REQUIRE(d != nullptr && out != nullptr, "null argument");
+  *out = nullptr;
+  MIA_REQUIRE(d->n_fft > 0 && d->n_fft % 2 == 0, "n_fft must be positive and even, got %d",
+              d->n_fft);
+  MIA_REQUIRE(d->hop_length > 0, "hop_length must be positive, got %d", d->hop_length);
+  MIA_REQUIRE(d->window != nullptr, "window is required");
+  MIA_REQUIRE(d->pad_mode >= 0 && d->pad_mode <= 2, "bad pad_mode %d", d->pad_mode);
+  if (!fft_size_supported(d->n_fft)) {
+    set_error("n_fft=%d has no compiled FFT plan (supported: 256, 400, 512, 800, 1024, 2048, "
+              "4096)", d->n_fft);
+    return MIA_ERR_UNSUPPORTED;
+  }
+  mia_plan* p = new mia_plan();
+  int rc = MIA_OK;
+  auto fail = [&](int code) {
+    plan_free(p);
+    return code;
+  };
+  if (hipGetDevice(&p->device) != hipSuccess) {
+    set_error("hipGetDevice failed (no GPU?)");
+    return fail(MIA_ERR_HIP);
+  }
+  p->n_fft = d->n_fft;
+  p->hop = d->hop_length;
+  p->center = d->center ? 1 : 0;
+  p->pad_mode = d->pad_mode;
+  p->power = d->power;
+  const int N = d->n_fft, bins = N / 2 + 1;
+  {
+    std::vector<float> w(d->window, d->window + N);
+    if ((rc = upload(&p->d_window, w)) != MIA_OK) return fail(rc);
+    std::vector<float2> tw((size_t)N);
+    for (int k = 0; k < N; ++k) {
+      // exact octant symmetry is not needed here; float64 libm then one rounding
+      const double a = -2.0 * M_PI * double(k) / double(N);
+      tw[(size_t)k] = {(float)std::cos(a), (float)std::sin(a)};
+    }
+    if ((rc = upload(&p->d_tw, tw)) != MIA_OK) return fail(rc);
+  }
+  if (d->n_mels > 0) {
+    if (d->mel_basis == nullptr) {
+      set_error("mel_basis is required when n_mels > 0");
+      return fail(MIA_ERR_INVALID);
+    }
+    p->n_mels = d->n_mels;
+    std::vector<int> lo((size_t)d->n_mels), len((size_t)d->n_mels), off((size_t)d->n_mels);
+    std::vector<float> wts;
+    for (int m = 0; m < d->n_mels; ++m) {
+      const float* row = d->mel_basis + (size_t)m * bins;
+      int first = -1, last = -1;
+      for (int k = 0; k < bins; ++k) {
+        if (row[k] != 0.0f) {
+          if (first < 0) first = k;
+          last = k;
+        }
+      }
+      lo[(size_t)m] = first < 0 ? 0 : first;
+      len[(size_t)m] = first < 0 ? 0 : last - first + 1;
+      off[(size_t)m] = (int)wts.size();
+      for (int k = 0; k < len[(size_t)m]; ++k) wts.push_back(row[first + k]);
+      if (len[(size_t)m] > p->max_row_len) p->max_row_len = len[(size_t)m];
+    }
+    p->nnz = (int)wts.size();
+    if ((rc = upload(&p->d_row_lo, lo)) != MIA_OK) return fail(rc);
+    if ((rc = upload(&p->d_row_len, len)) != MIA_OK) return fail(rc);
+    if ((rc = upload(&p->d_row_off, off)) != MIA_OK) return fail(rc);
+    if ((rc = upload(&p->d_wts, wts)) != MIA_OK) return fail(rc);
+  }
+  if (d->n_mfcc > 0) {
+    if (d->dct_basis == nullptr || d->n_mels <= 0) {
+      set_error("dct_basis and a mel stage are required when n_mfcc > 0");
+      return fail(MIA_ERR_INVALID);
+    }
+    p->n_mfcc = d->n_mfcc;
+    std::vector<float> c((size_t)d->n_mfcc * d->n_mels);
+    for (int k = 0; k < d->n_mfcc; ++k) {
+      const float l = d->lifter ? d->lifter[k] : 1.0f;
+      for (int n = 0; n < d->n_mels; ++n) {
+        c[(size_t)k * d->n_mels + n] = d->dct_basis[(size_t)k * d->n_mels + n] * l;
+      }
+    }
+    if ((rc = upload(&p->d_dct, c)) != MIA_OK) return fail(rc);
+  }
+  *out = p;
+  return MIA_OK;
+}
+
+int mia_plan_destroy(mia_plan* plan) {
+  plan_free(plan);
+  return MIA_OK;
+}
+
+int64_t mia_plan_num_frames(const mia_plan* plan, int64_t T) {
+  if (!plan) {
+    set_error("null plan");
+    return MIA_ERR_INVALID;
+  }
+  const int64_t padded = T + (plan->center ? 2 * (int64_t)(plan->n_fft / 2) : 0);
+  if (padded < plan->n_fft) {
+    set_error("Signal length (%lld) must be >= frame_length (%d). Consider padding the signal.",
+              (long long)padded, plan->n_fft);
+    return MIA_ERR_INVALID;
+  }
+  return 1 + (padded - plan->n_fft) / plan->hop;
+}
+
+// ----------------------------- hot path -------------------------------------
+
+}  // extern "C"
+
+static int fill_fwd(const mia_plan* plan, const float* y, int64_t B, int64_t T, FwdParams& p) {
+  MIA_REQUIRE(plan != nullptr, "null plan");
+  MIA_REQUIRE(y != nullptr || B == 0, "null input");
+  MIA_REQUIRE(B >= 0 && T >= 0, "negative shape");
+  const int64_t F = mia_plan_num_frames(plan, T);
+  if (F < 0) return (int)F;
+  const int pad = plan->center ? plan->n_fft / 2 : 0;
+  if (plan->pad_mode == MIA_PAD_REFLECT && pad > 0) {
+    MIA_REQUIRE(pad <= T - 1, "reflect padding of %d needs a signal longer than %d samples",
+                pad, pad);
+  }
+  if (plan->pad_mode == MIA_PAD_EDGE && pad > 0) MIA_REQUIRE(T >= 1, "empty signal");
+  std::memset(&p, 0, sizeof(p));
+  p.y = y;
+  p.B = B;
+  p.T = T;
+  p.F = F;
+  p.hop = plan->hop;
+  p.pad = pad;
+  p.pad_mode = plan->pad_mode;
+  p.win = plan->d_window;
+  p.tw = plan->d_tw;
+  p.scale = 1.0f;
+  return MIA_OK;
+}
+
+extern "C" {
+
+int mia_stft(const mia_plan* plan, const float* y, int64_t B, int64_t T, float scale, void* out,
+             void* stream) {
+  FwdParams p;
+  int rc = fill_fwd(plan, y, B, T, p);
+  if (rc != MIA_OK) return rc;
+  MIA_REQUIRE(out != nullptr || B == 0, "null output");
+  p.scale = scale;
+  p.cout = reinterpret_cast<float2*>(out);
+  return launch_forward(plan, p, 0, (hipStream_t)stream);
+}
+
+int mia_irfft_frames(const mia_plan* plan, const void* spec, int64_t B, int64_t F,
+                     int64_t stride_b, int64_t stride_bin, int64_t stride_frame, float* frames,
+                     void* stream) {
+  MIA_REQUIRE(plan != nullptr, "null plan");
+  MIA_REQUIRE(B >= 0 && F >= 0, "negative shape");
+  MIA_REQUIRE((spec && frames) || B == 0 || F == 0, "null buffer");
+  InvParams p{};
+  p.spec = reinterpret_cast<const float2*>(spec);
+  p.B = B;
+  p.F = F;
+  p.sb = stride_b;
+  p.sk = stride_bin;
+  p.sf = stride_frame;
+  p.tw = plan->d_tw;
+  p.frames = frames;
+  return launch_inverse(plan, p, (hipStream_t)stream);
+}
+
+int mia_overlap_add(const float* frames, const float* window, int64_t B, int64_t F, int n_fft,
+                    int hop, int64_t out_len, float scale, float* out, void* stream) {
+  MIA_REQUIRE(n_fft > 0, "n_fft must be positive, got %d", n_fft);
+  MIA_REQUIRE(hop > 0, "hop_length must be positive, got %d", hop);
+  MIA_REQUIRE(B >= 0 && F >= 0 && out_len >= 0, "negative shape");
+  MIA_REQUIRE(B <= 65535, "batch %lld exceeds 65535", (long long)B);
+  MIA_REQUIRE((frames && window && out) || B == 0 || out_len == 0, "null buffer");
+  return launch_overlap_add(frames, window, B, F, n_fft, hop, out_len, scale, out,
+                            (hipStream_t)stream);
+}
+
+size_t mia_istft_workspace_bytes(const mia_plan* plan, int64_t B, int64_t F) {
+  if (!plan || B <= 0 || F <= 0) return 0;
+  return sizeof(float) * (size_t)B * (size_t)F * (size_t)plan->n_fft;
+}
+
+int mia_istft(const mia_plan* plan, const void* spec, int64_t B, int64_t F, int64_t stride_b,
+              int64_t stride_bin, int64_t stride_frame, int64_t out_len, float scale, float* out,
+              void* workspace, size_t workspace_bytes, void* stream) {
+  MIA_REQUIRE(plan != nullptr, "null plan");
+  MIA_REQUIRE(workspace_bytes >= mia_istft_workspace_bytes(plan, B, F),
+              "workspace too small: %zu < %zu", workspace_bytes,
+              mia_istft_workspace_bytes(plan, B, F));
+  float* frames = reinterpret_cast<float*>(workspace);
+  int rc = mia_irfft_frames(plan, spec, B, F, stride_b, stride_bin, stride_frame, frames, stream);
+  if (rc != MIA_OK) return rc;
+  return mia_overlap_add(frames, plan->d_window, B, F, plan->n_fft, plan->hop, out_len, scale,
+                         out, stream);
+}
+
+}  // extern "C"
+
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+extern "C" size_t mia_mel_workspace_bytes(const mia_plan* plan, int64_t B, int64_t T) {
+  if (!plan || B <= 0) return 0;
+  const int64_t F = mia_plan_num_frames(plan, T);
+  if (F <= 0) return 0;
+  const int FT = forward_tile_frames(plan->n_fft, 1);
+  const int64_t tiles = (F + FT - 1) / FT;
+  return align256(sizeof(int) * (size_t)(B + 1)) + align256(sizeof(float) * (size_t)(B * tiles));
+}
+
+static int mel_forward(const mia_plan* plan, const float* y, int64_t B, int64_t T, int epilogue,
+                       float ref, float amin, float coef, float top_db, int per_clip, float* out,
+                       void* workspace, size_t workspace_bytes, hipStream_t s) {
+  FwdParams p;
+  int rc = fill_fwd(plan, y, B, T, p);
+  if (rc != MIA_OK) return rc;
+  MIA_REQUIRE(plan->n_mels > 0, "plan has no mel stage");
+  MIA_REQUIRE(out != nullptr || B == 0, "null output");
+  MIA_REQUIRE(epilogue >= 0 && epilogue <= 2, "bad epilogue %d", epilogue);
+  p.n_mels = plan->n_mels;
+  p.row_lo = plan->d_row_lo;
+  p.row_len = plan->d_row_len;
+  p.row_off = plan->d_row_off;
+  p.wts = plan->d_wts;
+  p.power = plan->power;
+  p.power_mode = plan->power == 2.0f ? 0 : (plan->power == 1.0f ? 1 : 2);
+  p.mout = out;
+  p.epi = epilogue;
+  p.amin = amin;
+  p.inv_ref = 1.0f / fmaxf(ref, amin);
+  p.coef = coef;
+  p.db_floor = coef * log10f(amin / fmaxf(ref, amin));
+  const bool clamp = epilogue == MIA_EPI_WHISPER || (epilogue == MIA_EPI_DB && top_db >= 0.0f);
+  const int FT = forward_tile_frames(plan->n_fft, 1);
+  const int tiles = (int)((p.F + FT - 1) / FT);
+  int* keys = nullptr;
+  float* tile_min = nullptr;
+  if (clamp && B > 0) {
+    MIA_REQUIRE(workspace != nullptr && workspace_bytes >= mia_mel_workspace_bytes(plan, B, T),
+                "workspace too small");
+    keys = reinterpret_cast<int*>(workspace);
+    tile_min = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) +
+                                        align256(sizeof(int) * (size_t)(B + 1)));
+    MIA_CHECK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(keys), kKeyMinusInf,
+                                    (size_t)B + 1, s));
+    p.clip_max_key = keys;
+    p.tile_min = tile_min;
+  }
+  rc = launch_forward(plan, p, 1, s);
+  if (rc != MIA_OK) return rc;
+  if (clamp && B > 0) {
+    const float top = epilogue == MIA_EPI_WHISPER ? 8.0f : top_db;
+    rc = launch_floor_tiles(out, B, plan->n_mels, p.F, tiles, FT, keys, tile_min, epilogue, top,
+                            per_clip, s);
+  }
+  return rc;
+}
+
+extern "C" {
+
+int mia_melspectrogram(const mia_plan* plan, const float* y, int64_t B, int64_t T, int epilogue,
+                       float ref, float amin, float coef, float top_db, int per_clip, float* out,
+                       void* workspace, size_t workspace_bytes, void* stream) {
+  return mel_forward(plan, y, B, T, epilogue, ref, amin, coef, top_db, per_clip, out, workspace,
+                     workspace_bytes, (hipStream_t)stream);
+}
+
+size_t mia_mfcc_workspace_bytes(const mia_plan* plan, int64_t B, int64_t T) {
+  if (!plan || B <= 0) return 0;
+  const int64_t F = mia_plan_num_frames(plan, T);
+  if (F <= 0) return 0;
+  return align256(mia_mel_workspace_bytes(plan, B, T)) +
+         align256(sizeof(float) * (size_t)B * (size_t)plan->n_mels * (size_t)F);
+}
+
+int mia_mfcc(const mia_plan* plan, const float* y, int64_t B, int64_t T, float top_db,
+             int per_clip, float* out, void* workspace, size_t workspace_bytes, void* stream) {
+  MIA_REQUIRE(plan != nullptr && plan->n_mfcc > 0, "plan has no DCT stage");
+  MIA_REQUIRE(B >= 0 && B <= 65535, "batch %lld out of range", (long long)B);
+  if (B == 0) return MIA_OK;
+  MIA_REQUIRE(workspace != nullptr && workspace_bytes >= mia_mfcc_workspace_bytes(plan, B, T),
+              "workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  const size_t melws = align256(mia_mel_workspace_bytes(plan, B, T));
+  float* sdb = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + melws);
+  const int64_t F = mia_plan_num_frames(plan, T);
+  if (F < 0) return (int)F;
+  // dB without the floor; the floor is applied while the DCT stages its slab.
+  FwdParams p;
+  int rc = fill_fwd(plan, y, B, T, p);
+  if (rc != MIA_OK) return rc;
+  p.n_mels = plan->n_mels;
+  p.row_lo = plan->d_row_lo;
+  p.row_len = plan->d_row_len;
+  p.row_off = plan->d_row_off;
+  p.wts = plan->d_wts;
+  p.power = plan->power;
+  p.power_mode = plan->power == 2.0f ? 0 : (plan->power == 1.0f ? 1 : 2);
+  p.mout = sdb;
+  p.epi = MIA_EPI_DB;
+  p.amin = 1e-10f;
+  p.inv_ref = 1.0f;
+  p.coef = 10.0f;
+  p.db_floor = 10.0f * log10f(1e-10f);
+  int* keys = reinterpret_cast<int*>(workspace);
+  float* tile_min = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) +
+                                             align256(sizeof(int) * (size_t)(B + 1)));
+  const bool clamp = top_db >= 0.0f;
+  MIA_CHECK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(keys), kKeyMinusInf,
+                                  (size_t)B + 1, s));
+  p.clip_max_key = keys;
+  p.tile_min = tile_min;
+  rc = launch_forward(plan, p, 1, s);
+  if (rc != MIA_OK) return rc;
+  if (clamp && !per_clip) {
+    // global maximum: fold keys[0..B) into keys[B]
+    rc = launch_reduce_keys(keys, B, s);
+    if (rc != MIA_OK) return rc;
+  }
+  return launch_dct2(sdb, B, plan->n_mels, F, plan->d_dct, plan->n_mfcc, out,
+                     clamp ? (per_clip ? keys : keys + B) : nullptr,
+                     (long long)(per_clip ? 1 : 0), top_db, s);
+}
+
+// --------------------------- stand-alone ops ---------------------------------
+
+int mia_pad_signal(const float* x, int64_t B, int64_t T, int64_t pad, int mode, float* out,
+                   void* stream) {
+  MIA_REQUIRE(B >= 0 && T >= 0, "negative shape");
+  MIA_REQUIRE(pad >= 0, "pad_length must be non-negative, got %lld", (long long)pad);
+  MIA_REQUIRE(mode >= 0 && mode <= 2, "Unknown pad_mode code %d", mode);
+  MIA_REQUIRE(B <= 65535, "batch %lld exceeds 65535", (long long)B);
+  if (mode == MIA_PAD_REFLECT && pad > 0) {
+    MIA_REQUIRE(pad <= T - 1, "reflect padding of %lld needs a signal longer than %lld samples",
+                (long long)pad, (long long)pad);
+  }
+  if (mode == MIA_PAD_EDGE && pad > 0) MIA_REQUIRE(T >= 1, "empty signal");
+  return launch_pad(x, B, T, pad, mode, out, (hipStream_t)stream);
+}
+
+int mia_frame_signal(const float* x, int64_t B, int64_t T, int frame_length, int hop, float* out,
+                     void* stream) {
+  MIA_REQUIRE(frame_length > 0, "frame_length must be positive, got %d", frame_length);
+  MIA_REQUIRE(hop > 0, "hop_length must be positive, got %d", hop);
+  MIA_REQUIRE(T >= frame_length,
+              "Signal length (%lld) must be >= frame_length (%d). Consider padding the signal.",
+              (long long)T, frame_length);
+  MIA_REQUIRE(B >= 0 && B <= 65535, "batch %lld out of range", (long long)B);
+  const int64_t F = 1 + (T - frame_length) / hop;
+  return launch_frame(x, B, T, F, frame_length, hop, out, (hipStream_t)stream);
+}
+
+int mia_to_db(const float* x, int64_t B, int64_t n, float ref, float amin, float coef,
+              float top_db, int per_clip, float* out, void* workspace, void* stream) {
+  MIA_REQUIRE(B >= 0 && n >= 0, "negative shape");
+  MIA_REQUIRE(B <= 65535, "batch %lld exceeds 65535", (long long)B);
+  MIA_REQUIRE(top_db < 0.0f || workspace != nullptr, "workspace required for top_db");
+  return launch_to_db(x, B, n, ref, amin, coef, top_db, per_clip, out,
+                      reinterpret_cast<int*>(workspace), (hipStream_t)stream);
+}
+
+int mia_dct2(const float* x, int64_t outer, int n_in, int64_t inner, const float* basis,
+             int n_out, float* out, void* stream) {
+  MIA_REQUIRE(outer >= 0 && inner >= 0 && n_in > 0 && n_out > 0, "bad shape");
+  MIA_REQUIRE(outer <= 65535, "outer %lld exceeds 65535", (long long)outer);
+  return launch_dct2(x, outer, n_in, inner, basis, n_out, out, nullptr, 0, 0.0f,
+                     (hipStream_t)stream);
+}
+
+int mia_magnitude(const void* z, int64_t n, float* out, void* stream) {
+  return launch_magnitude(reinterpret_cast<const float2*>(z), n, out, (hipStream_t)stream);
+}
+int mia_phase(const void* z, int64_t n, float* out, void* stream) {
+  return launch_phase(reinterpret_cast<const float2*>(z), n, out, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,107 @@
+// Internal declarations shared by the translation units of libmia_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/mia.h"
+
+namespace mia {
+
+void set_error(const char* fmt, ...);
+
+#define MIA_CHECK_HIP(expr)                                                        \
+  do {                                                                             \
+    hipError_t _e = (expr);                                                        \
+    if (_e != hipSuccess) {                                                        \
+      ::mia::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),      \
+                       __FILE__, __LINE__);                                        \
+      return MIA_ERR_HIP;                                                          \
+    }                                                                              \
+  } while (0)
+
+#define MIA_REQUIRE(cond, ...)                                                     \
+  do {                                                                             \
+    if (!(cond)) {                                                                 \
+      ::mia::set_error(__VA_ARGS__);                                               \
+      return MIA_ERR_INVALID;                                                      \
+    }                                                                              \
+  } while (0)
+
+// Sortable integer key of a float (monotone for all non-NaN values), so that a
+// float maximum can be taken with an integer atomicMax.
+__host__ __device__ inline int float_to_key(float f) {
+  int b = __builtin_bit_cast(int, f);
+  return b >= 0 ? b : (b ^ 0x7FFFFFFF);
+}
+__host__ __device__ inline float key_to_float(int k) {
+  int b = k >= 0 ? k : (k ^ 0x7FFFFFFF);
+  return __builtin_bit_cast(float, b);
+}
+constexpr int kKeyMinusInf = (int)0x80000000;  // below the key of -inf
+
+}  // namespace mia
+
+// The plan: per-device tables for one (n_fft, hop, window, mel, dct) setting.
+struct mia_plan {
+  int device = 0;
+  int n_fft = 0, hop = 0, center = 1, pad_mode = 0;
+  float* d_window = nullptr;     // n_fft
+  float2* d_tw = nullptr;        // n_fft entries exp(-2 pi i k / n_fft)
+  // mel band table (row-gather form of the filterbank)
+  int n_mels = 0, nnz = 0, max_row_len = 0;
+  int* d_row_lo = nullptr;
+  int* d_row_len = nullptr;
+  int* d_row_off = nullptr;
+  float* d_wts = nullptr;
+  float power = 2.0f;
+  // dct
+  int n_mfcc = 0;
+  float* d_dct = nullptr;        // n_mfcc x n_mels, rows pre-multiplied by the lifter
+};
+
+namespace mia {
+
+struct FwdParams {
+  const float* y;
+  long long B, T, F;
+  int hop, pad, pad_mode, tiles;
+  const float* win;
+  const float2* tw;
+  float scale;
+  float2* cout;
+  // mel epilogue
+  int n_mels;
+  const int* row_lo;
+  const int* row_len;
+  const int* row_off;
+  const float* wts;
+  int power_mode;  // 0: |X|^2, 1: |X|, 2: |X|^p
+  float power;
+  float* mout;
+  int epi;         // 0: none, 1: whisper log10 -> (y+4)/4, 2: dB
+  float amin, inv_ref, coef;
+  float db_floor;      // coef*log10(amin/max(ref,amin)), the value of clamped inputs
+  int* clip_max_key;   // B keys or nullptr
+  float* tile_min;     // B*tiles or nullptr
+};
+
+struct InvParams {
+  const float2* spec;
+  long long B, F;
+  long long sb, sk, sf;  // strides in complex elements: batch, bin, frame
+  const float2* tw;
+  float* frames;         // (B, F, N)
+  int tiles;
+};
+
+int launch_forward(const mia_plan* plan, const FwdParams& p, int mode, hipStream_t s);
+int launch_inverse(const mia_plan* plan, const InvParams& p, hipStream_t s);
+bool fft_size_supported(int n_fft);
+int forward_tile_frames(int n_fft, int mode);
+
+}  // namespace mia

@@ -1,0 +1,332 @@
+// Memory-bound helper kernels: gather overlap-add, pad, frame, dB conversion,
+// floor clamp of log features, DCT-II along a middle axis, |z| and arg z.
+#include "mia_internal.h"
+
+namespace mia {
+
+// ---------------------------------------------------------------------------
+// Overlap-add, gather form: one thread per output sample, frames visited in
+// ascending order, no atomics, so results are deterministic.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ola_kernel(const float* __restrict__ frames,
+                                                   const float* __restrict__ win, long long F,
+                                                   int n_fft, int hop, long long out_len,
+                                                   float scale, float* __restrict__ out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long b = blockIdx.y;
+  if (i >= out_len) return;
+  long long first = i - n_fft + 1;
+  first = first <= 0 ? 0 : (first + hop - 1) / hop;
+  long long last = i / hop;
+  if (last > F - 1) last = F - 1;
+  const float* __restrict__ fb = frames + b * F * (long long)n_fft;
+  float sum = 0.0f, wsum = 0.0f;
+  for (long long f = first; f <= last; ++f) {
+    const int s = (int)(i - f * hop);
+    const float w = win[s];
+    sum += w * fb[f * n_fft + s];
+    wsum += w * w;
+  }
+  out[b * out_len + i] = sum / fmaxf(wsum, 1e-8f) * scale;
+}
+
+int launch_overlap_add(const float* frames, const float* win, long long B, long long F,
+                       int n_fft, int hop, long long out_len, float scale, float* out,
+                       hipStream_t s) {
+  if (B <= 0 || out_len <= 0) return MIA_OK;
+  dim3 grid((unsigned)((out_len + 255) / 256), (unsigned)B);
+  hipLaunchKernelGGL(ola_kernel, grid, dim3(256), 0, s, frames, win, F, n_fft, hop, out_len,
+                     scale, out);
+  MIA_CHECK_HIP(hipGetLastError());
+  return MIA_OK;
+}
+
+// ---------------------------------------------------------------------------
+// pad / frame
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pad_kernel(const float* __restrict__ x, long long T,
+                                                   long long pad, int mode,
+                                                   float* __restrict__ out) {
+  const long long L = T + 2 * pad;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long b = blockIdx.y;
+  if (i >= L) return;
+  const long long src = i - pad;
+  float v;
+  if (src >= 0 && src < T) {
+    v = x[b * T + src];
+  } else if (mode == MIA_PAD_CONSTANT) {
+    v = 0.0f;
+  } else if (mode == MIA_PAD_EDGE) {
+    v = x[b * T + (src < 0 ? 0 : T - 1)];
+  } else {
+    const long long r = src < 0 ? -src : 2 * (T - 1) - src;
+    v = x[b * T + r];
+  }
+  out[b * L + i] = v;
+}
+
+__global__ __launch_bounds__(256) void frame_kernel(const float* __restrict__ x, long long T,
+                                                     long long F, int L, int hop,
+                                                     float* __restrict__ out) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long b = blockIdx.y;
+  if (idx >= F * L) return;
+  const long long f = idx / L;
+  const int i = (int)(idx - f * L);
+  out[b * F * L + idx] = x[b * T + f * hop + i];
+}
+
+// ---------------------------------------------------------------------------
+// dB conversion of an existing array with a per-row or global top_db floor
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void to_db_kernel(const float* __restrict__ x, long long n,
+                                                     float amin, float inv_ref, float coef,
+                                                     float* __restrict__ out,
+                                                     int* __restrict__ keys) {
+  const long long b = blockIdx.y;
+  float vmax = -INFINITY;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    const float v = coef * log10f(fmaxf(x[b * n + i], amin) * inv_ref);
+    out[b * n + i] = v;
+    vmax = fmaxf(vmax, v);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, off));
+  __shared__ float red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = vmax;
+  __syncthreads();
+  if (threadIdx.x == 0 && keys != nullptr) {
+    vmax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    atomicMax(keys + b, float_to_key(vmax));
+  }
+}
+
+// keys[B] -> keys[B] holds max over all rows (one workgroup).
+__global__ __launch_bounds__(256) void reduce_keys_kernel(int* __restrict__ keys, long long B) {
+  int k = kKeyMinusInf;
+  for (long long i = threadIdx.x; i < B; i += 256) k = max(k, keys[i]);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) k = max(k, __shfl_xor(k, off));
+  __shared__ int red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = k;
+  __syncthreads();
+  if (threadIdx.x == 0) keys[B] = max(max(red[0], red[1]), max(red[2], red[3]));
+}
+
+int launch_reduce_keys(int* keys, long long B, hipStream_t s) {
+  hipLaunchKernelGGL(reduce_keys_kernel, dim3(1), dim3(256), 0, s, keys, B);
+  MIA_CHECK_HIP(hipGetLastError());
+  return MIA_OK;
+}
+
+__device__ __forceinline__ float floor_from_key(int key, int epi, float top) {
+  const float gmax = key_to_float(key);
+  if (epi == MIA_EPI_WHISPER) return ((gmax - top) + 4.0f) * 0.25f;
+  return gmax - top;
+}
+
+__global__ __launch_bounds__(256) void floor_rows_kernel(float* __restrict__ x, long long n,
+                                                          const int* __restrict__ keys,
+                                                          long long key_stride, float top) {
+  const long long b = blockIdx.y;
+  const float thr = floor_from_key(keys[b * key_stride], MIA_EPI_DB, top);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    x[b * n + i] = fmaxf(x[b * n + i], thr);
+  }
+}
+
+// Floor clamp of the (B, n_mels, F) feature tensor, tile by tile with the
+// tiling of the forward kernel; a tile whose minimum is already above the
+// floor is skipped without touching memory.
+__global__ __launch_bounds__(256) void floor_tiles_kernel(float* __restrict__ x, int n_mels,
+                                                           long long F, int tiles, int FT,
+                                                           const int* __restrict__ keys,
+                                                           long long key_stride,
+                                                           const float* __restrict__ tile_min,
+                                                           int epi, float top) {
+  const long long b = blockIdx.x / tiles;
+  const int tile = blockIdx.x % tiles;
+  const float thr = floor_from_key(keys[b * key_stride], epi, top);
+  if (tile_min[blockIdx.x] >= thr) return;
+  const long long f0 = (long long)tile * FT;
+  const long long frem = F - f0;
+  const int fcount = frem < FT ? (int)frem : FT;
+  for (int idx = threadIdx.x; idx < n_mels * FT; idx += 256) {
+    const int m = idx / FT;
+    const int fl = idx - m * FT;
+    if (fl >= fcount) continue;
+    float* q = x + (b * n_mels + m) * F + f0 + fl;
+    *q = fmaxf(*q, thr);
+  }
+}
+
+int launch_to_db(const float* x, long long B, long long n, float ref, float amin, float coef,
+                 float top_db, int per_clip, float* out, int* keys, hipStream_t s) {
+  if (B <= 0 || n <= 0) return MIA_OK;
+  const bool clamp = top_db >= 0.0f;
+  if (clamp) {
+    MIA_CHECK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(keys), kKeyMinusInf,
+                                    (size_t)B + 1, s));
+  }
+  const float refv = fmaxf(ref, amin);
+  long long bx = (n + 256 * 8 - 1) / (256 * 8);
+  if (bx > 4096) bx = 4096;
+  if (bx < 1) bx = 1;
+  dim3 grid((unsigned)bx, (unsigned)B);
+  hipLaunchKernelGGL(to_db_kernel, grid, dim3(256), 0, s, x, n, amin, 1.0f / refv, coef, out,
+                     clamp ? keys : nullptr);
+  MIA_CHECK_HIP(hipGetLastError());
+  if (clamp) {
+    if (!per_clip) {
+      hipLaunchKernelGGL(reduce_keys_kernel, dim3(1), dim3(256), 0, s, keys, B);
+      MIA_CHECK_HIP(hipGetLastError());
+    }
+    hipLaunchKernelGGL(floor_rows_kernel, grid, dim3(256), 0, s, out, n,
+                       per_clip ? keys : keys + B, (long long)(per_clip ? 1 : 0), top_db);
+    MIA_CHECK_HIP(hipGetLastError());
+  }
+  return MIA_OK;
+}
+
+int launch_floor_tiles(float* x, long long B, int n_mels, long long F, int tiles, int FT,
+                       int* keys, const float* tile_min, int epi, float top, int per_clip,
+                       hipStream_t s) {
+  if (B <= 0 || tiles <= 0) return MIA_OK;
+  if (!per_clip) {
+    hipLaunchKernelGGL(reduce_keys_kernel, dim3(1), dim3(256), 0, s, keys, B);
+    MIA_CHECK_HIP(hipGetLastError());
+  }
+  hipLaunchKernelGGL(floor_tiles_kernel, dim3((unsigned)(B * tiles)), dim3(256), 0, s, x, n_mels,
+                     F, tiles, FT, per_clip ? keys : keys + B, (long long)(per_clip ? 1 : 0),
+                     tile_min, epi, top);
+  MIA_CHECK_HIP(hipGetLastError());
+  return MIA_OK;
+}
+
+// ---------------------------------------------------------------------------
+// DCT-II along the middle axis: out[o,k,i] = sum_n basis[k,n] * max(x[o,n,i], floor_o)
+// One workgroup = 64 consecutive `inner` positions of one `o`; the (n_in x 64)
+// slab is staged in LDS once and every wave produces a share of the outputs.
+// ---------------------------------------------------------------------------
+template <int KB>
+__global__ __launch_bounds__(256) void dct2_kernel(const float* __restrict__ x, int n_in,
+                                                    long long inner,
+                                                    const float* __restrict__ basis, int n_out,
+                                                    float* __restrict__ out,
+                                                    const int* __restrict__ keys,
+                                                    long long key_stride, float top) {
+  extern __shared__ float slab[];  // n_in x 64
+  const long long o = blockIdx.y;
+  const long long i0 = (long long)blockIdx.x * 64;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float thr = keys ? floor_from_key(keys[o * key_stride], MIA_EPI_DB, top) : -INFINITY;
+  const bool ok = i0 + lane < inner;
+  for (int n = wave; n < n_in; n += 4) {
+    float v = ok ? x[(o * n_in + n) * inner + i0 + lane] : 0.0f;
+    slab[n * 64 + lane] = fmaxf(v, thr);
+  }
+  __syncthreads();
+  for (int k0 = wave * KB; k0 < n_out; k0 += 4 * KB) {
+    float acc[KB];
+#pragma unroll
+    for (int q = 0; q < KB; ++q) acc[q] = 0.0f;
+    for (int n = 0; n < n_in; ++n) {
+      const float xv = slab[n * 64 + lane];
+#pragma unroll
+      for (int q = 0; q < KB; ++q) {
+        const int k = k0 + q < n_out ? k0 + q : n_out - 1;
+        acc[q] = fmaf(basis[k * n_in + n], xv, acc[q]);
+      }
+    }
+    if (ok) {
+#pragma unroll
+      for (int q = 0; q < KB; ++q) {
+        if (k0 + q < n_out) out[(o * n_out + k0 + q) * inner + i0 + lane] = acc[q];
+      }
+    }
+  }
+}
+
+int launch_dct2(const float* x, long long outer, int n_in, long long inner, const float* basis,
+                int n_out, float* out, const int* keys, long long key_stride, float top,
+                hipStream_t s) {
+  if (outer <= 0 || inner <= 0 || n_out <= 0) return MIA_OK;
+  const size_t lds = sizeof(float) * 64 * (size_t)n_in;
+  if (lds > 160 * 1024) {
+    set_error("dct: n_in=%d too large for the LDS slab", n_in);
+    return MIA_ERR_UNSUPPORTED;
+  }
+  auto kern = dct2_kernel<5>;
+  if (lds > 64 * 1024) {
+    MIA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  }
+  dim3 grid((unsigned)((inner + 63) / 64), (unsigned)outer);
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, x, n_in, inner, basis, n_out, out, keys,
+                     key_stride, top);
+  MIA_CHECK_HIP(hipGetLastError());
+  return MIA_OK;
+}
+
+// ---------------------------------------------------------------------------
+// |z|, arg z
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void magnitude_kernel(const float2* __restrict__ z,
+                                                         long long n, float* __restrict__ out) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    const float2 v = z[i];
+    out[i] = hypotf(v.x, v.y);
+  }
+}
+__global__ __launch_bounds__(256) void phase_kernel(const float2* __restrict__ z, long long n,
+                                                     float* __restrict__ out) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    const float2 v = z[i];
+    out[i] = atan2f(v.y, v.x);
+  }
+}
+
+static unsigned stream_grid(long long n) {
+  long long g = (n + 255) / 256;
+  if (g > 8192) g = 8192;
+  return (unsigned)(g < 1 ? 1 : g);
+}
+
+int launch_pad(const float* x, long long B, long long T, long long pad, int mode, float* out,
+               hipStream_t s) {
+  const long long L = T + 2 * pad;
+  if (B <= 0 || L <= 0) return MIA_OK;
+  dim3 grid((unsigned)((L + 255) / 256), (unsigned)B);
+  hipLaunchKernelGGL(pad_kernel, grid, dim3(256), 0, s, x, T, pad, mode, out);
+  MIA_CHECK_HIP(hipGetLastError());
+  return MIA_OK;
+}
+
+int launch_frame(const float* x, long long B, long long T, long long F, int L, int hop,
+                 float* out, hipStream_t s) {
+  if (B <= 0 || F <= 0) return MIA_OK;
+  dim3 grid((unsigned)((F * L + 255) / 256), (unsigned)B);
+  hipLaunchKernelGGL(frame_kernel, grid, dim3(256), 0, s, x, T, F, L, hop, out);
+  MIA_CHECK_HIP(hipGetLastError());
+  return MIA_OK;
+}
+
+int launch_magnitude(const float2* z, long long n, float* out, hipStream_t s) {
+  if (n <= 0) return MIA_OK;
+  hipLaunchKernelGGL(magnitude_kernel, dim3(stream_grid(n)), dim3(256), 0, s, z, n, out);
+  MIA_CHECK_HIP(hipGetLastError());
+  return MIA_OK;
+}
+int launch_phase(const float2* z, long long n, float* out, hipStream_t s) {
+  if (n <= 0) return MIA_OK;
+  hipLaunchKernelGGL(phase_kernel, dim3(stream_grid(n)), dim3(256), 0, s, z, n, out);
+  MIA_CHECK_HIP(hipGetLastError());
+  return MIA_OK;
+}
+
+}  // namespace mia

@@ -1,0 +1,418 @@
+// Forward path: fused pad + frame + window + real FFT, with either a complex
+// spectrum epilogue (stft) or a power -> mel band projection -> log epilogue
+// (melspectrogram / Whisper log-mel / dB).
+//
+// Work decomposition.  A "group" of T threads transforms one frame; a
+// workgroup holds G groups and walks ITERS frames per group, so one workgroup
+// produces FT = G*ITERS consecutive frames of one signal.  T = M / (2*R_last)
+// (M = n_fft/2) so that in the last Stockham pass every thread owns the two
+// butterflies j and M/R_last - j, whose outputs are exactly the bin pairs
+// (k, M-k) the real-FFT split step needs: the split runs in registers.
+//
+// In mel mode the power spectrum of the tile goes to an LDS tile P[FT][bins];
+// after a barrier the band projection runs with consecutive lanes on
+// consecutive frames, so the (n_mels, frames) output is written coalesced.
+#include "fft_engine.h"
+#include "mia_internal.h"
+
+namespace mia {
+
+// ---------------------------------------------------------------------------
+// Configuration of one n_fft: group size and radices.
+// ---------------------------------------------------------------------------
+template <int N_, int T_, int R0_, int R1_, int R2_, int PADQ_>
+struct FftCfg {
+  static constexpr int N = N_, M = N_ / 2, T = T_;
+  static constexpr int R0 = R0_, R1 = R1_, R2 = R2_;
+  static constexpr int NPASS = (R2_ > 1) ? 3 : 2;
+  static constexpr int RL = (NPASS == 3) ? R2_ : R1_;   // last radix
+  static constexpr int NSL = M / RL;                    // stride of last pass
+  static constexpr int PADQ = PADQ_;                    // one pad slot per PADQ
+  static constexpr int LBUF = M + M / PADQ_ + 2;
+  static constexpr bool MULTIWAVE = (T_ > 64);
+  static constexpr int GPW = MULTIWAVE ? 0 : 64 / T_;   // groups per wave
+  static_assert(R0_ * R1_ * R2_ == M, "radices must multiply to n_fft/2");
+  static_assert(2 * T_ * RL == M, "group size must be M/(2*R_last)");
+  static_assert((M / R0_) % T_ == 0, "pass 0 must split evenly");
+  static_assert(NPASS == 2 || (M / R1_) % T_ == 0, "pass 1 must split evenly");
+  static_assert(NSL % 2 == 0, "last stride must be even");
+
+  template <int WG>
+  static constexpr int groups() {
+    return MULTIWAVE ? WG / T_ : (WG / 64) * GPW;
+  }
+  static __device__ __forceinline__ void map(int tid, int& g, int& t, bool& active) {
+    if constexpr (MULTIWAVE) {
+      g = tid / T_;
+      t = tid % T_;
+      active = true;
+    } else {
+      const int lane = tid & 63, wave = tid >> 6;
+      g = wave * GPW + lane / T_;
+      t = lane % T_;
+      active = lane < GPW * T_;
+    }
+  }
+  // LDS slot of logical element i (padding breaks power-of-two strides).
+  static __device__ __forceinline__ int pos(int i) { return i + i / PADQ; }
+  template <int S>
+  static __device__ __forceinline__ int pos_strided(int j, int r) {
+    if constexpr (S % PADQ == 0) {
+      return pos(j) + r * (S + S / PADQ);
+    } else {
+      return pos(j + r * S);
+    }
+  }
+};
+
+template <class C>
+__device__ __forceinline__ void group_sync() {
+  if constexpr (C::MULTIWAVE) {
+    __syncthreads();
+  } else {
+    // The group lives inside one wave: program order plus in-order LDS
+    // service make the exchange visible; the fence stops the compiler from
+    // moving LDS accesses across the exchange point.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  }
+}
+
+// Which registers pair up in the split step for thread 0 of a group (it owns
+// the two self-paired butterflies 0 and NSL/2).  Slot s yields bins k and M-k.
+struct T0Pair {
+  bool u_b, v_b;   // operand lives in the B (second) butterfly
+  int ui, vi;      // register index
+  int k_half;      // k in units of NSL/2
+};
+template <int R>
+constexpr T0Pair t0_pair(int s) {
+  constexpr int NA = (R % 2 == 0) ? R / 2 : (R + 1) / 2;  // A-side slots
+  if (s < NA) {
+    return {false, false, s, (R - s) % R, 2 * s};
+  }
+  const int i = s - NA;
+  return {true, true, i, R - 1 - i, 1 + 2 * i};
+}
+
+// ---------------------------------------------------------------------------
+// Sample fetch with centre padding folded in.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float fetch_sample(const float* __restrict__ y, long long T,
+                                              long long i, int pad_mode) {
+  if (i >= 0 && i < T) return y[i];
+  if (pad_mode == MIA_PAD_CONSTANT) return 0.0f;
+  if (pad_mode == MIA_PAD_EDGE) return y[i < 0 ? 0 : T - 1];
+  long long r = i < 0 ? -i : 2 * (T - 1) - i;  // reflect without repeating the edge
+  r = r < 0 ? 0 : (r > T - 1 ? T - 1 : r);
+  return y[r];
+}
+
+template <class C, int MODE, int WG, int ITERS>
+__global__ __launch_bounds__(WG) void fwd_kernel(FwdParams p) {
+  constexpr int M = C::M, T = C::T, N = C::N;
+  constexpr int G = C::template groups<WG>();
+  constexpr int FT = G * ITERS;
+  constexpr int PS = (M + 1) | 1;  // odd row stride of the power tile
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float2* bufs = reinterpret_cast<float2*>(smem_raw);
+  float* P = reinterpret_cast<float*>(bufs + G * C::LBUF);
+
+  const int tid = threadIdx.x;
+  int g, t;
+  bool active;
+  C::map(tid, g, t, active);
+  float2* buf = bufs + (active ? g : 0) * C::LBUF;
+  const long long b = blockIdx.x / p.tiles;
+  const int tile = blockIdx.x % p.tiles;
+  const long long f0 = (long long)tile * FT;
+  const float* __restrict__ yb = p.y + b * p.T;
+  const float2* __restrict__ tw = p.tw;
+  const float2* __restrict__ win2 = reinterpret_cast<const float2*>(p.win);
+  const bool t0 = (t == 0);
+
+  if (active) {
+    for (int it = 0; it < ITERS; ++it) {
+      const int fl = it * G + g;
+      const long long f = f0 + fl;
+      const bool valid = f < p.F;
+      if (!C::MULTIWAVE && !valid) continue;
+      const long long s0 = f * p.hop - p.pad;  // first sample of the frame
+      const bool interior = valid && s0 >= 0 && s0 + N <= p.T;
+      const bool aligned8 = ((reinterpret_cast<uintptr_t>(yb + s0) & 7) == 0);
+
+      // ---- pass 0: windowed samples -> radix R0 -> LDS ----------------------
+      {
+        constexpr int R = C::R0, S = M / R, NB = S / T;
+        float2 v[NB][R];
+#pragma unroll
+        for (int bb = 0; bb < NB; ++bb) {
+          const int j = t + bb * T;
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            const int n = j + r * S;
+            float2 x;
+            if (interior) {
+              if (aligned8) {
+                x = *reinterpret_cast<const float2*>(yb + s0 + 2 * n);
+              } else {
+                x.x = yb[s0 + 2 * n];
+                x.y = yb[s0 + 2 * n + 1];
+              }
+            } else if (valid) {
+              x.x = fetch_sample(yb, p.T, s0 + 2 * n, p.pad_mode);
+              x.y = fetch_sample(yb, p.T, s0 + 2 * n + 1, p.pad_mode);
+            } else {
+              x = {0.0f, 0.0f};
+            }
+            const float2 w = win2[n];
+            v[bb][r] = {x.x * w.x, x.y * w.y};
+          }
+        }
+#pragma unroll
+        for (int bb = 0; bb < NB; ++bb) Dft<R>::run(v[bb]);
+#pragma unroll
+        for (int bb = 0; bb < NB; ++bb) {
+          const int j = t + bb * T;
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            const int slot = (C::PADQ == R) ? j * (R + 1) + r : C::pos(j * R + r);
+            buf[slot] = v[bb][r];
+          }
+        }
+      }
+      group_sync<C>();
+
+      // ---- middle pass (3-pass plans) ---------------------------------------
+      if constexpr (C::NPASS == 3) {
+        constexpr int R = C::R1, S = M / R, NB = S / T, NS = C::R0;
+        constexpr int TWS = 2 * (M / (NS * R));  // step in the n_fft-entry table
+        float2 v[NB][R];
+#pragma unroll
+        for (int bb = 0; bb < NB; ++bb) {
+          const int j = t + bb * T;
+          const int jm = j % NS;
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            float2 x = buf[C::template pos_strided<S>(j, r)];
+            if (r > 0) x = cmul(x, tw[jm * r * TWS]);
+            v[bb][r] = x;
+          }
+        }
+        group_sync<C>();
+#pragma unroll
+        for (int bb = 0; bb < NB; ++bb) Dft<R>::run(v[bb]);
+#pragma unroll
+        for (int bb = 0; bb < NB; ++bb) {
+          const int j = t + bb * T;
+          const int base = (j / NS) * NS * R + (j % NS);
+#pragma unroll
+          for (int r = 0; r < R; ++r) buf[C::template pos_strided<NS>(base, r)] = v[bb][r];
+        }
+        group_sync<C>();
+      }
+
+      // ---- last pass: butterflies t and NSL - t ------------------------------
+      constexpr int RL = C::RL, NSL = C::NSL;
+      float2 A[RL], Bv[RL];
+      {
+        const int jA = t;
+        const int jB = t0 ? NSL / 2 : NSL - t;
+#pragma unroll
+        for (int r = 0; r < RL; ++r) {
+          float2 xa = buf[C::template pos_strided<NSL>(jA, r)];
+          float2 xb = buf[C::template pos_strided<NSL>(jB, r)];
+          if (r > 0) {
+            xa = cmul(xa, tw[2 * jA * r]);
+            xb = cmul(xb, tw[2 * jB * r]);
+          }
+          A[r] = xa;
+          Bv[r] = xb;
+        }
+        group_sync<C>();  // next iteration overwrites buf
+        Dft<RL>::run(A);
+        Dft<RL>::run(Bv);
+      }
+
+      // ---- split step in registers: bins k and M-k ---------------------------
+      float2* __restrict__ crow =
+          (MODE == 0 && valid) ? p.cout + (b * p.F + f) * (long long)(M + 1) : nullptr;
+      float* __restrict__ prow = P + fl * PS;
+      const float half_scale = 0.5f * p.scale;
+      auto emit = [&](int k, float2 X) {
+        if constexpr (MODE == 0) {
+          if (valid) crow[k] = {X.x * half_scale, X.y * half_scale};
+        } else {
+          float pw = 0.25f * (X.x * X.x + X.y * X.y);
+          if (p.power_mode == 1) pw = sqrtf(pw);
+          else if (p.power_mode == 2) pw = powf(sqrtf(pw), p.power);
+          prow[k] = pw;
+        }
+      };
+      static_for<0, RL>([&](auto rc) {
+        constexpr int r = decltype(rc)::value;
+        constexpr T0Pair ps = t0_pair<RL>(r);
+        const float2 U0 = ps.u_b ? Bv[ps.ui] : A[ps.ui];
+        const float2 V0 = ps.v_b ? Bv[ps.vi] : A[ps.vi];
+        const float2 U = t0 ? U0 : A[r];
+        const float2 V = t0 ? V0 : Bv[RL - 1 - r];
+        const int k = t0 ? ps.k_half * (NSL / 2) : t + NSL * r;
+        const float2 w = tw[k];
+        // E = U + conj(V);  O = -i (U - conj(V));  X[k] = (E + w O)/2,
+        // X[M-k] = conj(E - w O)/2.
+        const float2 E = {U.x + V.x, U.y - V.y};
+        const float2 O = {U.y + V.y, V.x - U.x};
+        const float2 WO = cmul(O, w);
+        emit(k, {E.x + WO.x, E.y + WO.y});
+        emit(M - k, {E.x - WO.x, WO.y - E.y});
+      });
+      if (t0) {  // the self-paired bin M/2: X = conj(Z[M/2])
+        const float2 Z = (RL % 2 == 0) ? A[RL / 2] : Bv[(RL - 1) / 2];
+        emit(M / 2, {2.0f * Z.x, -2.0f * Z.y});
+      }
+    }
+  }
+
+  if constexpr (MODE == 1) {
+    __syncthreads();
+    const long long frem = p.F - f0;
+    const int fcount = frem < FT ? (int)frem : FT;
+    float vmax = -INFINITY, vmin = INFINITY;
+    for (int idx = tid; idx < p.n_mels * FT; idx += WG) {
+      const int m = idx / FT;
+      const int fl = idx - m * FT;
+      if (fl >= fcount) continue;
+      const int lo = p.row_lo[m], len = p.row_len[m];
+      const float* __restrict__ w = p.wts + p.row_off[m];
+      const float* __restrict__ pr = P + fl * PS + lo;
+      float acc = 0.0f;
+      for (int j = 0; j < len; ++j) acc = fmaf(w[j], pr[j], acc);
+      float outv = acc;
+      if (p.epi == MIA_EPI_WHISPER) {
+        // values at or below the 1e-10 floor give exactly log10(1e-10) = -10
+        const float yv = acc <= 1e-10f ? -10.0f : __log10f(acc);
+        vmax = fmaxf(vmax, yv);
+        outv = (yv + 4.0f) * 0.25f;
+        vmin = fminf(vmin, outv);
+      } else if (p.epi == MIA_EPI_DB) {
+        outv = acc <= p.amin ? p.db_floor : p.coef * __log10f(acc * p.inv_ref);
+        vmax = fmaxf(vmax, outv);
+        vmin = fminf(vmin, outv);
+      }
+      p.mout[(b * p.n_mels + m) * p.F + f0 + fl] = outv;
+    }
+    if (p.epi != MIA_EPI_NONE && p.clip_max_key != nullptr) {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        vmax = fmaxf(vmax, __shfl_xor(vmax, off));
+        vmin = fminf(vmin, __shfl_xor(vmin, off));
+      }
+      __shared__ float red[2][WG / 64];
+      if ((tid & 63) == 0) {
+        red[0][tid >> 6] = vmax;
+        red[1][tid >> 6] = vmin;
+      }
+      __syncthreads();
+      if (tid == 0) {
+#pragma unroll
+        for (int w = 1; w < WG / 64; ++w) {
+          vmax = fmaxf(vmax, red[0][w]);
+          vmin = fminf(vmin, red[1][w]);
+        }
+        atomicMax(p.clip_max_key + b, float_to_key(vmax));
+        p.tile_min[blockIdx.x] = vmin;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Size table and dispatch
+// ---------------------------------------------------------------------------
+//                    N     T   R0  R1  R2  PADQ
+using Cfg256 = FftCfg<256, 8, 16, 8, 1, 16>;
+using Cfg400 = FftCfg<400, 10, 20, 10, 1, 20>;
+using Cfg512 = FftCfg<512, 32, 8, 8, 4, 8>;
+using Cfg800 = FftCfg<800, 10, 20, 20, 1, 20>;
+using Cfg1024 = FftCfg<1024, 32, 8, 8, 8, 8>;
+using Cfg2048 = FftCfg<2048, 64, 16, 8, 8, 16>;
+using Cfg4096 = FftCfg<4096, 128, 16, 16, 8, 16>;
+
+template <class C, int MODE, int WG, int ITERS>
+static int launch_cfg(const FwdParams& p0, hipStream_t s) {
+  constexpr int G = C::template groups<WG>();
+  constexpr int FT = G * ITERS;
+  constexpr int PS = (C::M + 1) | 1;
+  FwdParams p = p0;
+  p.tiles = (int)((p.F + FT - 1) / FT);
+  const size_t lds = sizeof(float2) * G * C::LBUF + (MODE == 1 ? sizeof(float) * FT * PS : 0);
+  static_assert(sizeof(float2) * G * C::LBUF + (MODE == 1 ? sizeof(float) * FT * PS : 0) <=
+                    160 * 1024,
+                "LDS budget");
+  const long long blocks = p.B * p.tiles;
+  if (blocks <= 0) return MIA_OK;
+  if (blocks > 0x7fffffffLL) {
+    set_error("grid too large: %lld workgroups", blocks);
+    return MIA_ERR_INVALID;
+  }
+  auto kern = fwd_kernel<C, MODE, WG, ITERS>;
+  if (lds > 64 * 1024) {
+    MIA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(WG), lds, s, p);
+  MIA_CHECK_HIP(hipGetLastError());
+  return MIA_OK;
+}
+
+// Per size: workgroup threads and frames per group (ITERS), chosen so that the
+// group buffers plus the power tile stay under 80 KiB (two workgroups per CU).
+#define MIA_FWD_SIZES(X) \
+  X(256, Cfg256, 256, 2)  \
+  X(400, Cfg400, 256, 2)  \
+  X(512, Cfg512, 256, 4)  \
+  X(800, Cfg800, 128, 2)  \
+  X(1024, Cfg1024, 256, 2) \
+  X(2048, Cfg2048, 256, 2) \
+  X(4096, Cfg4096, 256, 2)
+
+template <int MODE>
+static int dispatch_mode(int n_fft, const FwdParams& p, hipStream_t s) {
+  switch (n_fft) {
+#define X(NFFT, CFG, WG, ITERS) \
+  case NFFT: return launch_cfg<CFG, MODE, WG, ITERS>(p, s);
+    MIA_FWD_SIZES(X)
+#undef X
+    default:
+      set_error("n_fft=%d has no compiled FFT plan (supported: 256, 400, 512, 800, 1024, "
+                "2048, 4096)", n_fft);
+      return MIA_ERR_UNSUPPORTED;
+  }
+}
+
+bool fft_size_supported(int n_fft) {
+  switch (n_fft) {
+#define X(NFFT, CFG, WG, ITERS) case NFFT:
+    MIA_FWD_SIZES(X)
+#undef X
+    return true;
+    default: return false;
+  }
+}
+
+int forward_tile_frames(int n_fft, int /*mode*/) {
+  switch (n_fft) {
+#define X(NFFT, CFG, WG, ITERS) \
+  case NFFT: return CFG::groups<WG>() * ITERS;
+    MIA_FWD_SIZES(X)
+#undef X
+    default: return 0;
+  }
+}
+
+int launch_forward(const mia_plan* plan, const FwdParams& p, int mode, hipStream_t s) {
+  return mode == 0 ? dispatch_mode<0>(plan->n_fft, p, s) : dispatch_mode<1>(plan->n_fft, p, s);
+}
+
+}  // namespace mia

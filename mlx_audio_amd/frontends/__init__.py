@@ -1,0 +1,11 @@
+"""Model-side feature functions built on the primitives: Whisper log-mel,
+HTDemucs spec / ispec, CLAP log-mel features."""
+
+from .clap import CLAPFeatureExtractor, clap_log_mel
+from .demucs import htdemucs_ispec, htdemucs_spec
+from .whisper import compute_log_mel_spectrogram, pad_or_trim
+
+__all__ = [
+    "compute_log_mel_spectrogram", "pad_or_trim", "htdemucs_spec", "htdemucs_ispec",
+    "clap_log_mel", "CLAPFeatureExtractor",
+]

@@ -1,0 +1,57 @@
+"""HTDemucs spectrogram front-end (mirror of
+python/mlx_audio/models/demucs/model.py:378-506)."""
+
+from __future__ import annotations
+
+import math
+
+import torch
+
+from .._runtime import as_device_f32
+from ..primitives.stft import _istft_raw, _stft_raw
+
+DEMUCS_N_FFT = 4096      # reference constants/audio_processing.py:15-17
+DEMUCS_HOP_LENGTH = 1024
+
+
+def htdemucs_spec(x, n_fft: int = DEMUCS_N_FFT, hop_length: int = DEMUCS_HOP_LENGTH):
+    """`HTDemucs._compute_stft` (model.py:378-417).
+
+    x [B, C, T] -> complex64 [B, C, n_fft//2, ceil(T/hop)]: zero-pad like
+    PyTorch demucs, reflect-padded STFT scaled by 1/sqrt(n_fft) (fused into the
+    kernel's store), Nyquist bin dropped, frames [2 : 2+le] kept.  The result
+    is a strided view of the kernel's (B*C, frames, bins) output.
+    """
+    x = as_device_f32(x, ndim_allowed=(3,))
+    B, C, T = x.shape
+    le = int(math.ceil(T / hop_length))
+    pad = hop_length // 2 * 3
+    xp = torch.nn.functional.pad(x, (pad, pad + le * hop_length - T))
+    raw = _stft_raw(xp.reshape(B * C, -1), n_fft, hop_length, n_fft, "hann", True, "reflect",
+                    scale=1.0 / math.sqrt(n_fft))          # (B*C, frames, bins)
+    spec = raw.transpose(1, 2)[:, :-1, 2:2 + le]           # (B*C, n_fft//2, le)
+    return spec.unflatten(0, (B, C))
+
+
+def htdemucs_ispec(m, length: int, n_fft: int = DEMUCS_N_FFT,
+                   hop_length: int = DEMUCS_HOP_LENGTH):
+    """`HTDemucs._mask_and_istft`, complex-as-channels branch (model.py:432-506).
+
+    m real [B, S, 2C, F, Tf] laid out (re_ch0, im_ch0, re_ch1, ...) ->
+    audio [B, S, C, length].  The sqrt(n_fft) factor is fused into the
+    overlap-add store.
+    """
+    m = as_device_f32(m, ndim_allowed=(5,))
+    B, S, C2, F, Tf = m.shape
+    C = C2 // 2
+    mr = m.reshape(B, S, C, 2, F, Tf)
+    # one zero Nyquist bin, two zero frames each side
+    z = torch.zeros((B * S * C, F + 1, Tf + 4), dtype=torch.complex64, device=m.device)
+    zv = torch.view_as_real(z)
+    zv[:, :F, 2:2 + Tf, 0] = mr[:, :, :, 0].reshape(B * S * C, F, Tf)
+    zv[:, :F, 2:2 + Tf, 1] = mr[:, :, :, 1].reshape(B * S * C, F, Tf)
+    pad = hop_length // 2 * 3
+    le = hop_length * int(math.ceil(length / hop_length)) + 2 * pad
+    y = _istft_raw(z, n_fft, hop_length, n_fft, "hann", le + n_fft, scale=math.sqrt(n_fft))
+    y = y[:, n_fft // 2:n_fft // 2 + le]
+    return y.reshape(B, S, C, -1)[:, :, :, pad:pad + length]

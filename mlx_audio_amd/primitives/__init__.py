@@ -1,0 +1,17 @@
+"""Audio DSP primitives on MI355X with the signatures of `mlx_audio.primitives`
+(reference python/mlx_audio/primitives/__init__.py:197-261, hot-path subset)."""
+
+from .._lib import HAS_HIP_EXT, has_hip_extensions
+from .convert import amplitude_to_db, db_to_amplitude, db_to_power, power_to_db
+from .mel import hz_to_mel, mel_filterbank, mel_to_hz, melspectrogram
+from .mfcc import dct, mfcc
+from .stft import check_nola, istft, magnitude, phase, stft
+from .windows import get_window
+
+__all__ = [
+    "HAS_HIP_EXT", "has_hip_extensions",
+    "stft", "istft", "magnitude", "phase", "check_nola", "get_window",
+    "mel_filterbank", "melspectrogram", "hz_to_mel", "mel_to_hz",
+    "dct", "mfcc",
+    "power_to_db", "amplitude_to_db", "db_to_power", "db_to_amplitude",
+]

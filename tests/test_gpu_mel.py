@@ -1,0 +1,230 @@
+"""GPU parity: melspectrogram / Whisper log-mel / dB / DCT / MFCC and the
+model-side front-ends against the CPU oracle.
+
+Stated float32 tolerances
+  * Whisper log-mel, (log10+4)/4 domain: max abs error <= 1e-4 (white noise and
+    speech-like inputs); tonal inputs are checked on the bins above the
+    float32 FFT noise floor (see test_logmel_tonal).
+  * mel power: rtol 1e-4 (+ atol 1e-5 relative to the largest value), the
+    reference's own mel tolerance (tests/parity/test_stft_parity.py:240-242).
+  * dB features: 1e-3 dB.  MFCC: 2e-3 (the reference's cross-language MFCC
+    tolerance is 1e-3 on smaller inputs).
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle.spectral as o
+
+pytestmark = pytest.mark.gpu
+
+
+def _noise(shape, seed):
+    return np.random.default_rng(seed).standard_normal(shape).astype(np.float32)
+
+
+def _speechlike(n, seed):
+    """Amplitude-modulated coloured noise with silent gaps."""
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal(n).astype(np.float32)
+    x = np.convolve(x, np.ones(8, np.float32) / 8, mode="same")
+    env = (np.sin(np.linspace(0, 40, n)) > 0.2).astype(np.float32)
+    env *= np.abs(np.sin(np.linspace(0, 7, n))).astype(np.float32)
+    return (x * env).astype(np.float32)
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(sr=22050, n_fft=2048, hop_length=512, n_mels=128),
+    dict(sr=16000, n_fft=400, hop_length=160, n_mels=80, fmin=0.0, fmax=8000.0),
+    dict(sr=16000, n_fft=400, hop_length=160, n_mels=128, fmin=0.0, fmax=8000.0),
+    dict(sr=48000, n_fft=1024, hop_length=480, n_mels=64, fmin=50, fmax=14000, htk=True),
+    dict(sr=44100, n_fft=4096, hop_length=1024, n_mels=128),
+    dict(sr=8000, n_fft=256, hop_length=64, n_mels=40),
+    dict(sr=16000, n_fft=512, hop_length=128, n_mels=64, norm=None, power=1.0),
+    dict(sr=16000, n_fft=800, hop_length=200, n_mels=80, power=1.5, pad_mode="reflect"),
+])
+def test_melspectrogram_matches_oracle(gpu, cfg):
+    from mlx_audio_amd.primitives import melspectrogram
+
+    y = _noise((3, 30011), seed=cfg["n_fft"])
+    got = melspectrogram(torch.from_numpy(y).to(gpu), **cfg).cpu().numpy()
+    ref = o.melspectrogram(y, **cfg)
+    assert got.shape == ref.shape
+    np.testing.assert_allclose(got, ref, rtol=1e-4, atol=1e-5 * ref.max())
+    got1 = melspectrogram(torch.from_numpy(y[0]).to(gpu), **cfg).cpu().numpy()
+    assert got1.shape == ref.shape[1:]
+    np.testing.assert_allclose(got1, ref[0], rtol=1e-4, atol=1e-5 * ref.max())
+
+
+@pytest.mark.parametrize("n_mels", [80, 128])
+def test_logmel_whisper_noise(gpu, n_mels):
+    from mlx_audio_amd.frontends import compute_log_mel_spectrogram
+
+    y = _noise((4, 480000), seed=1234)
+    yt = torch.from_numpy(y).to(gpu)
+    got = compute_log_mel_spectrogram(yt, n_mels=n_mels, per_clip=True).cpu().numpy()
+    assert got.shape == (4, n_mels, 3001)
+    for b in range(4):  # the reference's callers pass one clip at a time
+        ref = o.compute_log_mel_spectrogram(y[b], n_mels=n_mels)
+        assert np.abs(got[b] - ref).max() <= 1e-4
+    # default = the reference's array-global maximum
+    got_g = compute_log_mel_spectrogram(yt, n_mels=n_mels).cpu().numpy()
+    assert np.abs(got_g - o.compute_log_mel_spectrogram(y, n_mels=n_mels)).max() <= 1e-4
+    one = compute_log_mel_spectrogram(yt[0], n_mels=n_mels).cpu().numpy()
+    assert one.shape == (n_mels, 3001)
+    assert np.abs(one - o.compute_log_mel_spectrogram(y[0], n_mels=n_mels)).max() <= 1e-4
+
+
+def test_logmel_whisper_clamped_inputs(gpu):
+    """Inputs whose dynamic range exceeds 8 decades exercise the floor pass."""
+    from mlx_audio_amd.frontends import compute_log_mel_spectrogram
+
+    clips = np.stack([
+        _speechlike(160000, 1),
+        np.zeros(160000, np.float32),                                # silence -> exactly -1.5
+        _noise(160000, 3) * 1e-6,                                    # 1e-6-scaled
+        np.concatenate([np.zeros(80000, np.float32), _noise(80000, 4)]),
+    ])
+    got = compute_log_mel_spectrogram(torch.from_numpy(clips).to(gpu), n_mels=128,
+                                      per_clip=True).cpu().numpy()
+    for b in range(len(clips)):
+        ref = o.compute_log_mel_spectrogram(clips[b], n_mels=128)
+        assert np.abs(got[b] - ref).max() <= 1e-4, b
+    assert np.all(got[1] == -1.5)
+    got_g = compute_log_mel_spectrogram(torch.from_numpy(clips).to(gpu), n_mels=128)
+    ref_g = o.compute_log_mel_spectrogram(clips, n_mels=128)
+    assert np.abs(got_g.cpu().numpy() - ref_g).max() <= 1e-4
+
+
+def test_logmel_tonal(gpu):
+    """Three sines + noise at -40 dB.  Bins far below the peak sit on the
+    float32 FFT noise floor, where any two float32 FFTs (pocketfft included)
+    disagree; there both are compared with the float64 truth instead."""
+    from mlx_audio_amd.frontends import compute_log_mel_spectrogram
+
+    t = np.arange(480000) / 16000.0
+    y = (np.sin(2 * np.pi * 440 * t) + 0.5 * np.sin(2 * np.pi * 1000 * t) +
+         0.25 * np.sin(2 * np.pi * 3000 * t)).astype(np.float32)
+    y += 0.01 * _noise(480000, 9)
+    got = compute_log_mel_spectrogram(torch.from_numpy(y).to(gpu), n_mels=128).cpu().numpy()
+    ref32 = o.compute_log_mel_spectrogram(y, n_mels=128)
+    ref64 = o.compute_log_mel_spectrogram(y, n_mels=128, dtype=np.float64)
+    assert np.abs(got - ref32).max() <= 1e-4
+    assert np.abs(got - ref64).max() <= max(1e-4, 2 * np.abs(ref32 - ref64).max())
+
+
+def test_power_to_db_and_friends(gpu):
+    from mlx_audio_amd.primitives import (amplitude_to_db, db_to_amplitude, db_to_power,
+                                          power_to_db)
+
+    p = torch.tensor([1.0, 10.0, 100.0], device=gpu)
+    np.testing.assert_allclose(power_to_db(p).cpu().numpy(), [0, 10, 20], atol=1e-5)
+    np.testing.assert_allclose(amplitude_to_db(p, amin=1e-5).cpu().numpy(), [0, 20, 40],
+                               atol=1e-5)
+    clip = power_to_db(torch.tensor([1e-20, 1.0, 100.0], device=gpu)).cpu().numpy()
+    np.testing.assert_allclose(clip, [-60, 0, 20], atol=1e-5)
+    S = np.abs(_noise((3, 64, 200), 5)) ** 2 * np.array([1e-6, 1.0, 1e3], np.float32)[:, None, None]
+    St = torch.from_numpy(S).to(gpu)
+    np.testing.assert_allclose(power_to_db(St).cpu().numpy(), o.power_to_db(S), atol=1e-4)
+    np.testing.assert_allclose(power_to_db(St, top_db=None).cpu().numpy(),
+                               o.power_to_db(S, top_db=None), atol=1e-4)
+    per = power_to_db(St, per_clip=True).cpu().numpy()
+    for b in range(3):
+        np.testing.assert_allclose(per[b], o.power_to_db(S[b]), atol=1e-4)
+    np.testing.assert_allclose(power_to_db(St, ref=torch.max).cpu().numpy(),
+                               o.power_to_db(S, ref=np.max), atol=1e-4)
+    np.testing.assert_allclose(amplitude_to_db(St).cpu().numpy(), o.amplitude_to_db(S), atol=1e-4)
+    with pytest.raises(ValueError, match="top_db must be positive"):
+        power_to_db(St, top_db=0)
+    db = power_to_db(St, top_db=None)
+    np.testing.assert_allclose(db_to_power(db).cpu().numpy(), np.maximum(S, 1e-10), rtol=1e-4)
+    np.testing.assert_allclose(db_to_amplitude(amplitude_to_db(St, top_db=None)).cpu().numpy(),
+                               np.maximum(S, 1e-5), rtol=1e-4)
+
+
+def test_dct(gpu):
+    import scipy.fft
+
+    from mlx_audio_amd.primitives import dct
+
+    x = _noise((3, 128, 77), 6)
+    xt = torch.from_numpy(x).to(gpu)
+    got = dct(xt, n=40, axis=1).cpu().numpy()
+    np.testing.assert_allclose(got, o.dct(x, n=40, axis=1), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(got, scipy.fft.dct(x, type=2, axis=1, norm="ortho")[:, :40],
+                               rtol=1e-4, atol=1e-4)
+    assert dct(xt, n=20).shape == (3, 128, 20)
+    np.testing.assert_allclose(dct(xt, axis=-1).cpu().numpy(), o.dct(x), rtol=1e-5, atol=2e-5)
+    np.testing.assert_allclose(dct(xt, axis=0, norm=None).cpu().numpy(),
+                               o.dct(x, axis=0, norm=None), rtol=1e-5, atol=2e-5)
+    with pytest.raises(ValueError, match="Only DCT type 2"):
+        dct(xt, type=3)
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(sr=16000, n_mfcc=40, n_fft=2048, hop_length=512, n_mels=128),
+    dict(sr=22050, n_mfcc=13, lifter=22),
+    dict(sr=16000, n_mfcc=20, n_fft=400, hop_length=160, n_mels=80),
+])
+def test_mfcc_matches_oracle(gpu, cfg):
+    from mlx_audio_amd.primitives import mfcc
+
+    y = np.stack([_noise(48000, 7), _speechlike(48000, 8) * 3.0])
+    yt = torch.from_numpy(y).to(gpu)
+    got = mfcc(yt, **cfg).cpu().numpy()
+    ref = o.mfcc(y, **cfg)
+    assert got.shape == ref.shape
+    np.testing.assert_allclose(got, ref, rtol=1e-5, atol=2e-3)
+    per = mfcc(yt, per_clip=True, **cfg).cpu().numpy()
+    for b in range(2):
+        np.testing.assert_allclose(per[b], o.mfcc(y[b], **cfg), rtol=1e-5, atol=2e-3)
+    # pre-computed log-mel path
+    S = o.power_to_db(o.melspectrogram(y[0], sr=16000, n_fft=512, n_mels=40))
+    np.testing.assert_allclose(mfcc(S=torch.from_numpy(S).to(gpu), n_mfcc=13).cpu().numpy(),
+                               o.mfcc(S=S, n_mfcc=13), rtol=0, atol=1e-3)
+    with pytest.raises(ValueError, match="n_mfcc must be positive"):
+        mfcc(yt, n_mfcc=0)
+
+
+def test_htdemucs_spec_ispec(gpu):
+    from mlx_audio_amd.frontends import htdemucs_ispec, htdemucs_spec
+
+    x = (_noise((1, 2, 44100 * 3 + 17), 42) * 0.1).astype(np.float32)
+    got = htdemucs_spec(torch.from_numpy(x).to(gpu))
+    ref = o.htdemucs_spec(x)
+    assert tuple(got.shape) == ref.shape == (1, 2, 2048, 130)
+    assert np.abs(got.cpu().numpy() - ref).max() <= 2e-6 * np.abs(ref).max()
+    assert np.abs(got.cpu().numpy() - ref).mean() < 1e-3  # the reference's MAE bound
+    # inverse: build the [B, S, 2C, F, T] real layout from the spectrum, S=1
+    B, C, F, Tf = ref.shape
+    m = np.stack([ref.real, ref.imag], axis=2).reshape(B, 1, 2 * C, F, Tf).astype(np.float32)
+    rec = htdemucs_ispec(torch.from_numpy(m).to(gpu), length=x.shape[-1]).cpu().numpy()
+    ref_rec = o.htdemucs_ispec(m, length=x.shape[-1])
+    assert rec.shape == ref_rec.shape == (1, 1, 2, x.shape[-1])
+    assert np.abs(rec - ref_rec).max() <= 1e-5
+    # away from the clip ends the chain reproduces the input (the dropped
+    # Nyquist bin costs a little energy, hence not exact)
+    assert np.abs(rec[0, 0, :, 8192:-8192] - x[0, :, 8192:-8192]).max() < 5e-3
+
+
+def test_clap_features(gpu):
+    from mlx_audio_amd.frontends import CLAPFeatureExtractor, clap_log_mel
+
+    y = _noise((2, 480000), 7)
+    got = clap_log_mel(torch.from_numpy(y).to(gpu)).cpu().numpy()
+    ref = o.clap_mel(y)
+    assert got.shape == ref.shape == (2, 1001, 64)
+    np.testing.assert_allclose(got, ref, rtol=0, atol=1e-3)
+    fe = CLAPFeatureExtractor(rng=np.random.default_rng(0))
+    short = _noise(100000, 8)
+    long = _noise(480000 + 96000, 9)
+    out = fe([torch.from_numpy(short), torch.from_numpy(long)])
+    assert tuple(out["input_features"].shape) == (2, 4, 1001, 64)
+    assert out["is_longer"].cpu().numpy().tolist() == [[False], [True]]
+    np.testing.assert_allclose(out["input_features"][0].cpu().numpy(), o.clap_padded_mel(short),
+                               rtol=0, atol=1e-3)
+    full = o.clap_mel(long)
+    crops = out["input_features"][1].cpu().numpy()
+    for c in range(1, 4):  # each crop is a contiguous window of the full mel
+        d = [np.abs(full[s:s + 1001] - crops[c]).max() for s in range(full.shape[0] - 1000)]
+        assert min(d) <= 1e-3

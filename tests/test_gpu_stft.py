@@ -1,0 +1,203 @@
+"""GPU parity: stft / istft / stand-alone ops against the CPU oracle.
+
+Tolerances: complex spectra are compared relative to the frame-level scale
+(an FFT's float32 error is proportional to the largest bin, not to each bin):
+max |S_gpu - S_oracle| <= 2e-6 * max|S_oracle| (the oracle itself sits ~1e-6
+from a float64 transform).  The reference's own tolerance for STFT magnitudes
+is rtol 1e-4 / atol 1e-5 (tests/parity/test_stft_parity.py:82); both are
+asserted.
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle.spectral as o
+
+pytestmark = pytest.mark.gpu
+
+SIZES = [256, 400, 512, 800, 1024, 2048, 4096]
+
+
+def _sig(n, seed=0, batch=None):
+    rng = np.random.default_rng(seed)
+    shape = (n,) if batch is None else (batch, n)
+    return rng.standard_normal(shape).astype(np.float32)
+
+
+def _rel(a, b):
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+@pytest.mark.parametrize("n_fft", SIZES)
+@pytest.mark.parametrize("pad_mode", ["constant", "reflect", "edge"])
+def test_stft_matches_oracle(gpu, n_fft, pad_mode):
+    from mlx_audio_amd.primitives import stft
+
+    y = _sig(3 * n_fft + 137, seed=n_fft, batch=3)
+    hop = n_fft // 4 if n_fft != 400 else 160
+    S = stft(torch.from_numpy(y).to(gpu), n_fft=n_fft, hop_length=hop, pad_mode=pad_mode)
+    ref = o.stft(y, n_fft=n_fft, hop_length=hop, pad_mode=pad_mode)
+    assert tuple(S.shape) == ref.shape
+    assert S.dtype == torch.complex64
+    got = S.cpu().numpy()
+    assert _rel(got, ref) <= 2e-6
+    np.testing.assert_allclose(np.abs(got), np.abs(ref), rtol=1e-4, atol=1e-5 * np.sqrt(n_fft))
+
+
+def test_stft_1d_odd_length_and_center_false(gpu):
+    from mlx_audio_amd.primitives import stft
+
+    y = _sig(22051, seed=1)
+    for center in (True, False):
+        S = stft(torch.from_numpy(y).to(gpu), n_fft=2048, hop_length=512, center=center)
+        ref = o.stft(y, n_fft=2048, hop_length=512, center=center)
+        assert tuple(S.shape) == ref.shape
+        assert _rel(S.cpu().numpy(), ref) <= 2e-6
+
+
+def test_stft_odd_batch_stride_unaligned(gpu):
+    """Odd signal length makes every second row 8-byte misaligned."""
+    from mlx_audio_amd.primitives import stft
+
+    y = _sig(4097, seed=2, batch=4)
+    S = stft(torch.from_numpy(y).to(gpu), n_fft=512, hop_length=128)
+    assert _rel(S.cpu().numpy(), o.stft(y, n_fft=512, hop_length=128)) <= 2e-6
+
+
+def test_stft_win_length_and_windows(gpu):
+    from mlx_audio_amd.primitives import stft
+
+    y = _sig(8000, seed=3)
+    for window, win_length in [("hamming", 300), ("blackman", 400), ("bartlett", 256),
+                               ("boxcar", 400)]:
+        S = stft(torch.from_numpy(y).to(gpu), n_fft=400, hop_length=160, win_length=win_length,
+                 window=window)
+        ref = o.stft(y, n_fft=400, hop_length=160, win_length=win_length, window=window)
+        assert _rel(S.cpu().numpy(), ref) <= 2e-6
+    w = np.random.default_rng(0).random(400).astype(np.float32)
+    S = stft(torch.from_numpy(y).to(gpu), n_fft=400, hop_length=100, window=torch.from_numpy(w))
+    assert _rel(S.cpu().numpy(), o.stft(y, n_fft=400, hop_length=100, window=w)) <= 2e-6
+
+
+def test_stft_sine_peak_bin(gpu):
+    """440 Hz sine at 22050 Hz, the reference's first parity case."""
+    from mlx_audio_amd.primitives import stft
+
+    sr = 22050
+    t = np.linspace(0, 1.0, sr, endpoint=False)
+    y = np.sin(2 * np.pi * 440.0 * t).astype(np.float32)
+    S = stft(torch.from_numpy(y).to(gpu), n_fft=2048, hop_length=512).cpu().numpy()
+    ref = o.stft(y, n_fft=2048, hop_length=512)
+    np.testing.assert_allclose(np.abs(S), np.abs(ref), rtol=1e-4, atol=1.5e-4)
+    assert int(np.abs(S[:, 20]).argmax()) == round(440.0 * 2048 / sr)
+
+
+def test_stft_errors(gpu):
+    from mlx_audio_amd.primitives import stft
+
+    y = torch.zeros(1000, device=gpu)
+    with pytest.raises(ValueError, match="hop_length must be positive"):
+        stft(y, n_fft=512, hop_length=0)
+    with pytest.raises(ValueError, match="must be <= n_fft"):
+        stft(y, n_fft=512, win_length=1024)
+    with pytest.raises(ValueError, match="Unknown pad_mode"):
+        stft(y, n_fft=512, pad_mode="wrap")
+    with pytest.raises(ValueError, match="must be >= frame_length"):
+        stft(torch.zeros(100, device=gpu), n_fft=512, center=False)
+    with pytest.raises(NotImplementedError):
+        stft(y, n_fft=300)
+    # 10 ms at 44.1 kHz is shorter than n_fft but centre padding makes it long enough
+    assert stft(torch.zeros(441, device=gpu), n_fft=512).shape == (257, 4)
+
+
+@pytest.mark.parametrize("n_fft", SIZES)
+def test_istft_matches_oracle(gpu, n_fft):
+    from mlx_audio_amd.primitives import istft
+
+    rng = np.random.default_rng(n_fft)
+    hop = n_fft // 4 if n_fft != 400 else 160
+    F = 23
+    spec = (rng.standard_normal((2, n_fft // 2 + 1, F)) +
+            1j * rng.standard_normal((2, n_fft // 2 + 1, F))).astype(np.complex64)
+    ref = o.istft(spec, hop_length=hop)
+    got = istft(torch.from_numpy(spec).to(gpu), hop_length=hop).cpu().numpy()
+    assert got.shape == ref.shape
+    # hann-squared sums are tiny at the very edges, which amplifies round-off there
+    assert np.abs(got - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())
+    ref_l = o.istft(spec, hop_length=hop, length=hop * 20 + 3)
+    got_l = istft(torch.from_numpy(spec).to(gpu), hop_length=hop, length=hop * 20 + 3)
+    assert got_l.shape == ref_l.shape
+    assert np.abs(got_l.cpu().numpy() - ref_l).max() <= 1e-5 * max(1.0, np.abs(ref_l).max())
+
+
+@pytest.mark.parametrize("n_fft,hop", [(2048, 512), (400, 160), (4096, 1024), (1024, 480)])
+def test_roundtrip_snr(gpu, n_fft, hop):
+    """STFT -> iSTFT round trip: SNR >= 100 dB (float32), plus the reference's
+    own tolerance rtol 1e-3 / atol 1e-4 (test_stft_parity.py:103-118)."""
+    from mlx_audio_amd.primitives import istft, stft
+
+    y = _sig(22050 * 2, seed=42, batch=2)
+    yt = torch.from_numpy(y).to(gpu)
+    S = stft(yt, n_fft=n_fft, hop_length=hop)
+    rec = istft(S, hop_length=hop, length=y.shape[1]).cpu().numpy()
+    snr = 10 * np.log10((y.astype(np.float64) ** 2).sum() /
+                        ((y.astype(np.float64) - rec) ** 2).sum())
+    assert snr >= 100.0, snr
+    np.testing.assert_allclose(rec, y, rtol=1e-3, atol=1e-4)
+
+
+def test_istft_center_false_and_2d(gpu):
+    from mlx_audio_amd.primitives import istft, stft
+
+    y = _sig(8192, seed=5)
+    S = stft(torch.from_numpy(y).to(gpu), n_fft=512, hop_length=128, center=False)
+    ref_S = o.stft(y, n_fft=512, hop_length=128, center=False)
+    for length in (None, 5000, 9000):
+        ref = o.istft(ref_S, hop_length=128, center=False, length=length)
+        got = istft(S, hop_length=128, center=False, length=length).cpu().numpy()
+        assert got.shape == ref.shape
+        # Without centre padding the squared-window sum falls to ~1e-9 at both
+        # ends, so the division amplifies float32 round-off there: tight check
+        # on the interior, loose check on the first/last frame.
+        n = min(len(ref), 8192)
+        inner = slice(512, n - 512)
+        assert np.abs(got[inner] - ref[inner]).max() <= 2e-5 * max(1.0, np.abs(ref).max())
+        np.testing.assert_allclose(got, ref, rtol=0, atol=5e-3)
+    with pytest.raises(ValueError, match="2D or 3D"):
+        istft(torch.zeros((2, 2, 257, 4), dtype=torch.complex64, device=gpu))
+
+
+def test_ext_ops(gpu):
+    from mlx_audio_amd.primitives import ext
+
+    y = _sig(1000, seed=7, batch=3)
+    yt = torch.from_numpy(y).to(gpu)
+    for mode in ("constant", "edge", "reflect"):
+        np.testing.assert_array_equal(ext.pad_signal(yt, 200, mode).cpu().numpy(),
+                                      o.pad_signal(y, 200, mode))
+    assert ext.pad_signal(yt, 0) is not None
+    with pytest.raises(ValueError):
+        ext.pad_signal(yt, 1000, "reflect")
+    np.testing.assert_array_equal(ext.frame_signal(yt, 256, 100).cpu().numpy(),
+                                  o.frame_signal(y, 256, 100))
+    with pytest.raises(ValueError, match="must be >= frame_length"):
+        ext.frame_signal(yt, 2000, 100)
+    frames = np.random.default_rng(0).standard_normal((2, 9, 64)).astype(np.float32)
+    win = o.get_window("hann", 64)
+    got = ext.overlap_add(torch.from_numpy(frames).to(gpu), torch.from_numpy(win).to(gpu), 16,
+                          64 + 8 * 16 + 5).cpu().numpy()
+    ref = o.overlap_add(frames, win, 16, 64 + 8 * 16 + 5)
+    np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-6)
+    np.testing.assert_array_equal(ext.generate_window("hann", 400, True).cpu().numpy(),
+                                  o.get_window("hann", 400))
+    np.testing.assert_array_equal(ext.get_dct_matrix(13, 40).cpu().numpy(), o.dct_matrix(13, 40))
+
+
+def test_magnitude_phase(gpu):
+    from mlx_audio_amd.primitives import magnitude, phase
+
+    rng = np.random.default_rng(0)
+    z = (rng.standard_normal((5, 33)) + 1j * rng.standard_normal((5, 33))).astype(np.complex64)
+    zt = torch.from_numpy(z).to(gpu)
+    np.testing.assert_allclose(magnitude(zt).cpu().numpy(), np.abs(z), rtol=1e-6)
+    np.testing.assert_allclose(phase(zt).cpu().numpy(), np.angle(z), rtol=1e-5, atol=1e-6)
