@@ -25,8 +25,8 @@ int launch_pad(const float*, long long, long long, long long, int, float*, hipSt
 int launch_frame(const float*, long long, long long, long long, int, int, float*, hipStream_t);
 int launch_to_db(const float*, long long, long long, float, float, float, float, int, float*,
                  int*, hipStream_t);
-int launch_floor_tiles(float*, long long, int, long long, int, int, int*, const float*, int,
-                       float, int, hipStream_t);
+int launch_floor_clips(float*, long long, long long, int*, const int*, int, float, int,
+                       hipStream_t);
 int launch_dct2(const float*, long long, int, long long, const float*, int, float*, const int*,
                 long long, float, hipStream_t);
 int launch_magnitude(const float2*, long long, float*, hipStream_t);
@@ -185,6 +185,10 @@ static void plan_free(mia_plan* p) {
   (void)hipFree(p->d_row_off);
   (void)hipFree(p->d_wts);
   (void)hipFree(p->d_dct);
+  (void)hipFree(p->d_tw2);
+  (void)hipFree(p->d_tws);
+  (void)hipFree(p->d_wpad);
+  (void)hipFree(p->d_mpart);
   delete p;
 }
 
@@ -268,6 +272,57 @@ int mia_plan_create(const mia_plan_desc* d, mia_plan** out) {
     if ((rc = upload(&p->d_row_len, len)) != MIA_OK) return fail(rc);
     if ((rc = upload(&p->d_row_off, off)) != MIA_OK) return fail(rc);
     if ((rc = upload(&p->d_wts, wts)) != MIA_OK) return fail(rc);
+    if (N == 400 && d->hop_length == 160 && p->max_row_len <= 16) {
+      // tables of the lane-per-frame kernel (logmel400.hip)
+      std::vector<float2> tw2(25 * 8), tws(13 * 8);
+      for (int k1 = 0; k1 < 25; ++k1) {
+        for (int t = 0; t < 8; ++t) {
+          const double a = -2.0 * M_PI * double((t * k1) % 200) / 200.0;
+          tw2[(size_t)k1 * 8 + t] = {(float)std::cos(a), (float)std::sin(a)};
+        }
+      }
+      for (int k1 = 0; k1 < 13; ++k1) {
+        for (int k2 = 0; k2 < 8; ++k2) {
+          const double a = -2.0 * M_PI * double(k1 + 25 * k2) / 400.0;
+          tws[(size_t)k1 * 8 + k2] = {(float)std::cos(a), (float)std::sin(a)};
+        }
+      }
+      std::vector<float> wpad((size_t)d->n_mels * 16, 0.0f);
+      for (int m = 0; m < d->n_mels; ++m) {
+        for (int j = 0; j < len[(size_t)m]; ++j) {
+          wpad[(size_t)m * 16 + j] = wts[(size_t)off[(size_t)m] + j];
+        }
+      }
+      // Deal mel rows to the 8 waves so that (pass-2 work + mel work) is even:
+      // waves 0-3 own 4 butterflies, wave 4 three, waves 5-7 two.
+      const double bfly_cost = 150.0;
+      const double pre[8] = {4 * bfly_cost, 4 * bfly_cost, 4 * bfly_cost, 4 * bfly_cost,
+                             3 * bfly_cost, 2 * bfly_cost, 2 * bfly_cost, 2 * bfly_cost};
+      double total = 0.0;
+      std::vector<double> cost((size_t)d->n_mels);
+      for (int m = 0; m < d->n_mels; ++m) {
+        cost[(size_t)m] = 10.0 + 2.0 * len[(size_t)m];
+        total += cost[(size_t)m];
+      }
+      for (double c : pre) total += c;
+      const double target = total / 8.0;
+      std::vector<int> mpart(9, d->n_mels);
+      mpart[0] = 0;
+      int m = 0;
+      for (int w = 0; w < 8; ++w) {
+        double acc = pre[w];
+        mpart[(size_t)w] = m;
+        while (m < d->n_mels && (w == 7 || acc + 0.5 * cost[(size_t)m] <= target)) {
+          acc += cost[(size_t)m];
+          ++m;
+        }
+      }
+      mpart[8] = d->n_mels;
+      if ((rc = upload(&p->d_tw2, tw2)) != MIA_OK) return fail(rc);
+      if ((rc = upload(&p->d_tws, tws)) != MIA_OK) return fail(rc);
+      if ((rc = upload(&p->d_wpad, wpad)) != MIA_OK) return fail(rc);
+      if ((rc = upload(&p->d_mpart, mpart)) != MIA_OK) return fail(rc);
+    }
   }
   if (d->n_mfcc > 0) {
     if (d->dct_basis == nullptr || d->n_mels <= 0) {
@@ -406,9 +461,16 @@ extern "C" size_t mia_mel_workspace_bytes(const mia_plan* plan, int64_t B, int64
   if (!plan || B <= 0) return 0;
   const int64_t F = mia_plan_num_frames(plan, T);
   if (F <= 0) return 0;
-  const int FT = forward_tile_frames(plan->n_fft, 1);
-  const int64_t tiles = (F + FT - 1) / FT;
-  return align256(sizeof(int) * (size_t)(B + 1)) + align256(sizeof(float) * (size_t)(B * tiles));
+  return 2 * align256(sizeof(int) * (size_t)(B + 1));
+}
+
+// The lane-per-frame kernel when the plan has its tables, else the generic one.
+static int forward_mel_dispatch(const mia_plan* plan, const FwdParams& p, hipStream_t s) {
+  if (plan->d_tw2 != nullptr) {
+    W400Tables tb{plan->d_tw2, plan->d_tws, plan->d_wpad, plan->d_mpart};
+    return launch_logmel400(p, tb, s);
+  }
+  return launch_forward(plan, p, 1, s);
 }
 
 static int mel_forward(const mia_plan* plan, const float* y, int64_t B, int64_t T, int epilogue,
@@ -434,27 +496,27 @@ static int mel_forward(const mia_plan* plan, const float* y, int64_t B, int64_t 
   p.coef = coef;
   p.db_floor = coef * log10f(amin / fmaxf(ref, amin));
   const bool clamp = epilogue == MIA_EPI_WHISPER || (epilogue == MIA_EPI_DB && top_db >= 0.0f);
-  const int FT = forward_tile_frames(plan->n_fft, 1);
-  const int tiles = (int)((p.F + FT - 1) / FT);
-  int* keys = nullptr;
-  float* tile_min = nullptr;
+  int* max_keys = nullptr;
+  int* min_keys = nullptr;
   if (clamp && B > 0) {
     MIA_REQUIRE(workspace != nullptr && workspace_bytes >= mia_mel_workspace_bytes(plan, B, T),
                 "workspace too small");
-    keys = reinterpret_cast<int*>(workspace);
-    tile_min = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) +
-                                        align256(sizeof(int) * (size_t)(B + 1)));
-    MIA_CHECK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(keys), kKeyMinusInf,
+    max_keys = reinterpret_cast<int*>(workspace);
+    min_keys = reinterpret_cast<int*>(reinterpret_cast<char*>(workspace) +
+                                      align256(sizeof(int) * (size_t)(B + 1)));
+    MIA_CHECK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(max_keys), kKeyMinusInf,
                                     (size_t)B + 1, s));
-    p.clip_max_key = keys;
-    p.tile_min = tile_min;
+    MIA_CHECK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(min_keys), kKeyPlusInf,
+                                    (size_t)B + 1, s));
+    p.clip_max_key = max_keys;
+    p.clip_min_key = min_keys;
   }
-  rc = launch_forward(plan, p, 1, s);
+  rc = forward_mel_dispatch(plan, p, s);
   if (rc != MIA_OK) return rc;
   if (clamp && B > 0) {
     const float top = epilogue == MIA_EPI_WHISPER ? 8.0f : top_db;
-    rc = launch_floor_tiles(out, B, plan->n_mels, p.F, tiles, FT, keys, tile_min, epilogue, top,
-                            per_clip, s);
+    rc = launch_floor_clips(out, B, (long long)plan->n_mels * p.F, max_keys, min_keys, epilogue,
+                            top, per_clip, s);
   }
   return rc;
 }
@@ -506,14 +568,16 @@ int mia_mfcc(const mia_plan* plan, const float* y, int64_t B, int64_t T, float t
   p.coef = 10.0f;
   p.db_floor = 10.0f * log10f(1e-10f);
   int* keys = reinterpret_cast<int*>(workspace);
-  float* tile_min = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) +
-                                             align256(sizeof(int) * (size_t)(B + 1)));
+  int* min_keys = reinterpret_cast<int*>(reinterpret_cast<char*>(workspace) +
+                                         align256(sizeof(int) * (size_t)(B + 1)));
   const bool clamp = top_db >= 0.0f;
   MIA_CHECK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(keys), kKeyMinusInf,
                                   (size_t)B + 1, s));
+  MIA_CHECK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(min_keys), kKeyPlusInf,
+                                  (size_t)B + 1, s));
   p.clip_max_key = keys;
-  p.tile_min = tile_min;
-  rc = launch_forward(plan, p, 1, s);
+  p.clip_min_key = min_keys;
+  rc = forward_mel_dispatch(plan, p, s);
   if (rc != MIA_OK) return rc;
   if (clamp && !per_clip) {
     // global maximum: fold keys[0..B) into keys[B]

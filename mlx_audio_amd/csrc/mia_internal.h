@@ -43,6 +43,22 @@ __host__ __device__ inline float key_to_float(int k) {
   return __builtin_bit_cast(float, b);
 }
 constexpr int kKeyMinusInf = (int)0x80000000;  // below the key of -inf
+constexpr int kKeyPlusInf = 0x7FFFFFFF;        // above the key of +inf
+
+// Sample i of a signal of length T with centre padding folded in.
+__device__ __forceinline__ float fetch_sample(const float* __restrict__ y, long long T,
+                                              long long i, int pad_mode) {
+  if (i >= 0 && i < T) return y[i];
+  if (pad_mode == MIA_PAD_CONSTANT) return 0.0f;
+  if (pad_mode == MIA_PAD_EDGE) return y[i < 0 ? 0 : T - 1];
+  long long r = i < 0 ? -i : 2 * (T - 1) - i;  // reflect without repeating the edge
+  r = r < 0 ? 0 : (r > T - 1 ? T - 1 : r);
+  return y[r];
+}
+__device__ __forceinline__ float fetch_sample_any(const float* __restrict__ y, long long T,
+                                                  long long i, int pad_mode) {
+  return fetch_sample(y, T, i, pad_mode);
+}
 
 }  // namespace mia
 
@@ -62,6 +78,11 @@ struct mia_plan {
   // dct
   int n_mfcc = 0;
   float* d_dct = nullptr;        // n_mfcc x n_mels, rows pre-multiplied by the lifter
+  // extra tables of the n_fft = 400 / hop = 160 kernel (null when not applicable)
+  float2* d_tw2 = nullptr;       // [25][8]  exp(-2 pi i t k1 / 200)
+  float2* d_tws = nullptr;       // [13][8]  exp(-2 pi i (k1 + 25 k2) / 400)
+  float* d_wpad = nullptr;       // [n_mels][16] filter rows, zero padded
+  int* d_mpart = nullptr;        // [9] mel rows owned by each of the 8 waves
 };
 
 namespace mia {
@@ -86,8 +107,15 @@ struct FwdParams {
   int epi;         // 0: none, 1: whisper log10 -> (y+4)/4, 2: dB
   float amin, inv_ref, coef;
   float db_floor;      // coef*log10(amin/max(ref,amin)), the value of clamped inputs
-  int* clip_max_key;   // B keys or nullptr
-  float* tile_min;     // B*tiles or nullptr
+  int* clip_max_key;   // B (+1) keys of the per-clip maximum, or nullptr
+  int* clip_min_key;   // B keys of the per-clip minimum of the stored values
+};
+
+struct W400Tables {
+  const float2* tw2;
+  const float2* tws;
+  const float* wpad;
+  const int* mpart;
 };
 
 struct InvParams {
@@ -101,6 +129,7 @@ struct InvParams {
 
 int launch_forward(const mia_plan* plan, const FwdParams& p, int mode, hipStream_t s);
 int launch_inverse(const mia_plan* plan, const InvParams& p, hipStream_t s);
+int launch_logmel400(const FwdParams& p, const W400Tables& tb, hipStream_t s);
 bool fft_size_supported(int n_fft);
 int forward_tile_frames(int n_fft, int mode);
 

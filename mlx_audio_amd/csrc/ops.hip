@@ -138,28 +138,22 @@ __global__ __launch_bounds__(256) void floor_rows_kernel(float* __restrict__ x, 
   }
 }
 
-// Floor clamp of the (B, n_mels, F) feature tensor, tile by tile with the
-// tiling of the forward kernel; a tile whose minimum is already above the
-// floor is skipped without touching memory.
-__global__ __launch_bounds__(256) void floor_tiles_kernel(float* __restrict__ x, int n_mels,
-                                                           long long F, int tiles, int FT,
-                                                           const int* __restrict__ keys,
+// Floor clamp of the (B, n) feature tensor.  A clip whose minimum is already
+// above its floor is skipped without touching memory (the common case: the
+// log-mel range of most inputs is narrower than the clamp window).
+__global__ __launch_bounds__(256) void floor_clips_kernel(float* __restrict__ x, long long n,
+                                                           const int* __restrict__ max_keys,
                                                            long long key_stride,
-                                                           const float* __restrict__ tile_min,
+                                                           const int* __restrict__ min_keys,
                                                            int epi, float top) {
-  const long long b = blockIdx.x / tiles;
-  const int tile = blockIdx.x % tiles;
-  const float thr = floor_from_key(keys[b * key_stride], epi, top);
-  if (tile_min[blockIdx.x] >= thr) return;
-  const long long f0 = (long long)tile * FT;
-  const long long frem = F - f0;
-  const int fcount = frem < FT ? (int)frem : FT;
-  for (int idx = threadIdx.x; idx < n_mels * FT; idx += 256) {
-    const int m = idx / FT;
-    const int fl = idx - m * FT;
-    if (fl >= fcount) continue;
-    float* q = x + (b * n_mels + m) * F + f0 + fl;
-    *q = fmaxf(*q, thr);
+  const long long b = blockIdx.y;
+  const float thr = floor_from_key(max_keys[b * key_stride], epi, top);
+  if (key_to_float(min_keys[b]) >= thr) return;
+  float* __restrict__ xb = x + b * n;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    const float v = xb[i];
+    if (v < thr) xb[i] = thr;
   }
 }
 
@@ -191,17 +185,18 @@ int launch_to_db(const float* x, long long B, long long n, float ref, float amin
   return MIA_OK;
 }
 
-int launch_floor_tiles(float* x, long long B, int n_mels, long long F, int tiles, int FT,
-                       int* keys, const float* tile_min, int epi, float top, int per_clip,
-                       hipStream_t s) {
-  if (B <= 0 || tiles <= 0) return MIA_OK;
+int launch_floor_clips(float* x, long long B, long long n, int* max_keys, const int* min_keys,
+                       int epi, float top, int per_clip, hipStream_t s) {
+  if (B <= 0 || n <= 0) return MIA_OK;
   if (!per_clip) {
-    hipLaunchKernelGGL(reduce_keys_kernel, dim3(1), dim3(256), 0, s, keys, B);
+    hipLaunchKernelGGL(reduce_keys_kernel, dim3(1), dim3(256), 0, s, max_keys, B);
     MIA_CHECK_HIP(hipGetLastError());
   }
-  hipLaunchKernelGGL(floor_tiles_kernel, dim3((unsigned)(B * tiles)), dim3(256), 0, s, x, n_mels,
-                     F, tiles, FT, per_clip ? keys : keys + B, (long long)(per_clip ? 1 : 0),
-                     tile_min, epi, top);
+  long long bx = (n + 256 * 16 - 1) / (256 * 16);
+  if (bx > 64) bx = 64;
+  hipLaunchKernelGGL(floor_clips_kernel, dim3((unsigned)bx, (unsigned)B), dim3(256), 0, s, x, n,
+                     per_clip ? max_keys : max_keys + B, (long long)(per_clip ? 1 : 0),
+                     min_keys, epi, top);
   MIA_CHECK_HIP(hipGetLastError());
   return MIA_OK;
 }

@@ -96,19 +96,6 @@ constexpr T0Pair t0_pair(int s) {
   return {true, true, i, R - 1 - i, 1 + 2 * i};
 }
 
-// ---------------------------------------------------------------------------
-// Sample fetch with centre padding folded in.
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ float fetch_sample(const float* __restrict__ y, long long T,
-                                              long long i, int pad_mode) {
-  if (i >= 0 && i < T) return y[i];
-  if (pad_mode == MIA_PAD_CONSTANT) return 0.0f;
-  if (pad_mode == MIA_PAD_EDGE) return y[i < 0 ? 0 : T - 1];
-  long long r = i < 0 ? -i : 2 * (T - 1) - i;  // reflect without repeating the edge
-  r = r < 0 ? 0 : (r > T - 1 ? T - 1 : r);
-  return y[r];
-}
-
 template <class C, int MODE, int WG, int ITERS>
 __global__ __launch_bounds__(WG) void fwd_kernel(FwdParams p) {
   constexpr int M = C::M, T = C::T, N = C::N;
@@ -321,7 +308,7 @@ __global__ __launch_bounds__(WG) void fwd_kernel(FwdParams p) {
           vmin = fminf(vmin, red[1][w]);
         }
         atomicMax(p.clip_max_key + b, float_to_key(vmax));
-        p.tile_min[blockIdx.x] = vmin;
+        atomicMin(p.clip_min_key + b, float_to_key(vmin));
       }
     }
   }
