@@ -187,8 +187,8 @@ static void plan_free(mia_plan* p) {
   (void)hipFree(p->d_dct);
   (void)hipFree(p->d_tw2);
   (void)hipFree(p->d_tws);
-  (void)hipFree(p->d_wpad);
-  (void)hipFree(p->d_mpart);
+  (void)hipFree(p->d_sweep_meta);
+  (void)hipFree(p->d_sweep_w);
   delete p;
 }
 
@@ -199,6 +199,138 @@ static int upload(Tp** dst, const std::vector<Tp>& src) {
   if (!src.empty()) {
     MIA_CHECK_HIP(hipMemcpy(*dst, src.data(), sizeof(Tp) * src.size(), hipMemcpyHostToDevice));
   }
+  return MIA_OK;
+}
+
+
+// Tables of the lane-per-frame n_fft=400 / hop=160 kernel (logmel400.hip).
+// Returns MIA_OK and leaves the plan without them when the filterbank is not
+// of the "two taps per bin" triangular form the sweep needs.
+static int build_w400_tables(mia_plan* p, const float* basis, int n_mels, int bins) {
+  // segment s(k) of every bin: the bin feeds the rising edge of filter s and
+  // the falling edge of filter s-1
+  std::vector<int> seg((size_t)bins);
+  std::vector<float> wr((size_t)bins, 0.0f), wf((size_t)bins, 0.0f);
+  int cur = 0;
+  for (int k = 0; k < bins; ++k) {
+    int nz[3], n = 0;
+    for (int m = 0; m < n_mels && n < 3; ++m) {
+      if (basis[(size_t)m * bins + k] != 0.0f) nz[n++] = m;
+    }
+    if (n == 0) {
+      seg[(size_t)k] = cur;
+    } else if (n == 1) {
+      const int s = nz[0] >= cur ? nz[0] : nz[0] + 1;
+      if (s < cur) return MIA_OK;
+      cur = s;
+      seg[(size_t)k] = s;
+    } else if (n == 2 && nz[1] == nz[0] + 1 && nz[1] >= cur) {
+      cur = nz[1];
+      seg[(size_t)k] = cur;
+    } else {
+      return MIA_OK;
+    }
+    const int s = seg[(size_t)k];
+    if (s < n_mels) wr[(size_t)k] = basis[(size_t)s * bins + k];
+    if (s >= 1 && s - 1 < n_mels) wf[(size_t)k] = basis[(size_t)(s - 1) * bins + k];
+  }
+  for (int m = 0; m < n_mels; ++m) {  // exact reconstruction or no fast path
+    for (int k = 0; k < bins; ++k) {
+      const int s = seg[(size_t)k];
+      const float v = (m == s) ? wr[(size_t)k] : ((m == s - 1) ? wf[(size_t)k] : 0.0f);
+      if (v != basis[(size_t)m * bins + k]) return MIA_OK;
+    }
+  }
+  // Deal filters to the 8 waves so that pass-2 work + sweep work is even
+  // (waves 0-3 own 4 butterflies, wave 4 three, waves 5-7 two); a wave may
+  // hold at most 64 bins.
+  const double bfly = 150.0, per_mel = 40.0, per_bin = 3.0;
+  const double pre[8] = {4 * bfly, 4 * bfly, 4 * bfly, 4 * bfly, 3 * bfly, 2 * bfly, 2 * bfly,
+                         2 * bfly};
+  std::vector<int> seg_count((size_t)n_mels + 1, 0), seg_first((size_t)n_mels + 1, -1);
+  for (int k = 0; k < bins; ++k) {
+    const int s = seg[(size_t)k];
+    if (s > n_mels) return MIA_OK;
+    if (seg_first[(size_t)s] < 0) seg_first[(size_t)s] = k;
+    if (++seg_count[(size_t)s] > 15) return MIA_OK;
+  }
+  auto bins_of = [&](int m0, int m1, int& klo) {  // bins with m0 <= s(k) <= m1
+    int lo = -1, n = 0;
+    for (int s = m0; s <= m1; ++s) {
+      if (seg_count[(size_t)s] > 0 && lo < 0) lo = seg_first[(size_t)s];
+      n += seg_count[(size_t)s];
+    }
+    klo = lo < 0 ? 0 : lo;
+    return n;
+  };
+  // Smallest per-wave cost bound for which a greedy left-to-right deal fits all
+  // filters into 8 waves (<= 32 filters and <= 64 bins per wave).
+  auto deal = [&](double bound, int* starts) {
+    int m = 0;
+    for (int w = 0; w < 8; ++w) {
+      starts[w] = m;
+      int klo = 0;
+      while (m < n_mels && m - starts[w] < 32) {
+        const int nb = bins_of(starts[w], m + 1, klo);
+        if (nb > 64) break;
+        const double c = pre[w] + (m + 1 - starts[w]) * per_mel + nb * per_bin;
+        if (c > bound && m > starts[w]) break;
+        if (c > bound && pre[w] + per_mel + nb * per_bin > bound) break;
+        ++m;
+      }
+    }
+    starts[8] = m;
+    return m == n_mels;
+  };
+  int starts[9];
+  double lo_b = 0.0, hi_b = 1e9;
+  if (!deal(hi_b, starts)) return MIA_OK;  // does not fit the per-wave limits
+  for (int iter = 0; iter < 60; ++iter) {
+    const double mid = 0.5 * (lo_b + hi_b);
+    if (deal(mid, starts)) hi_b = mid; else lo_b = mid;
+  }
+  deal(hi_b, starts);
+  std::vector<int> meta(8 * 16, 0);
+  std::vector<float> sw(8 * 2 * 64, 0.0f);
+  for (int w = 0; w < 8; ++w) {
+    const int m0 = starts[w];
+    const int m1 = starts[w + 1];  // wave owns filters [m0, m1) = segments m0..m1
+    int klo = 0;
+    int* mt = &meta[(size_t)w * 16];
+    mt[2] = m0;
+    if (m1 == m0) continue;  // nseg = 0: nothing to do
+    const int nb = bins_of(m0, m1, klo);
+    mt[0] = klo;
+    mt[1] = m1 - m0 + 1;
+    int i = 0;
+    for (int s = m0; s <= m1; ++s) {
+      mt[4 + (s - m0) / 8] |= seg_count[(size_t)s] << (4 * ((s - m0) % 8));
+      for (int j = 0; j < seg_count[(size_t)s]; ++j, ++i) {
+        const int k = seg_first[(size_t)s] + j;
+        sw[(size_t)(2 * w + 0) * 64 + i] = wf[(size_t)k];
+        sw[(size_t)(2 * w + 1) * 64 + i] = wr[(size_t)k];
+      }
+    }
+    if (i != nb) return MIA_OK;
+  }
+  std::vector<float2> tw2(25 * 8), tws(13 * 8);
+  for (int k1 = 0; k1 < 25; ++k1) {
+    for (int t = 0; t < 8; ++t) {
+      const double a = -2.0 * M_PI * double((t * k1) % 200) / 200.0;
+      tw2[(size_t)k1 * 8 + t] = {(float)std::cos(a), (float)std::sin(a)};
+    }
+  }
+  for (int k1 = 0; k1 < 13; ++k1) {
+    for (int k2 = 0; k2 < 8; ++k2) {
+      const double a = -2.0 * M_PI * double(k1 + 25 * k2) / 400.0;
+      tws[(size_t)k1 * 8 + k2] = {(float)std::cos(a), (float)std::sin(a)};
+    }
+  }
+  int rc;
+  if ((rc = upload(&p->d_tw2, tw2)) != MIA_OK) return rc;
+  if ((rc = upload(&p->d_tws, tws)) != MIA_OK) return rc;
+  if ((rc = upload(&p->d_sweep_meta, meta)) != MIA_OK) return rc;
+  if ((rc = upload(&p->d_sweep_w, sw)) != MIA_OK) return rc;
   return MIA_OK;
 }
 
@@ -272,56 +404,9 @@ int mia_plan_create(const mia_plan_desc* d, mia_plan** out) {
     if ((rc = upload(&p->d_row_len, len)) != MIA_OK) return fail(rc);
     if ((rc = upload(&p->d_row_off, off)) != MIA_OK) return fail(rc);
     if ((rc = upload(&p->d_wts, wts)) != MIA_OK) return fail(rc);
-    if (N == 400 && d->hop_length == 160 && p->max_row_len <= 16) {
-      // tables of the lane-per-frame kernel (logmel400.hip)
-      std::vector<float2> tw2(25 * 8), tws(13 * 8);
-      for (int k1 = 0; k1 < 25; ++k1) {
-        for (int t = 0; t < 8; ++t) {
-          const double a = -2.0 * M_PI * double((t * k1) % 200) / 200.0;
-          tw2[(size_t)k1 * 8 + t] = {(float)std::cos(a), (float)std::sin(a)};
-        }
-      }
-      for (int k1 = 0; k1 < 13; ++k1) {
-        for (int k2 = 0; k2 < 8; ++k2) {
-          const double a = -2.0 * M_PI * double(k1 + 25 * k2) / 400.0;
-          tws[(size_t)k1 * 8 + k2] = {(float)std::cos(a), (float)std::sin(a)};
-        }
-      }
-      std::vector<float> wpad((size_t)d->n_mels * 16, 0.0f);
-      for (int m = 0; m < d->n_mels; ++m) {
-        for (int j = 0; j < len[(size_t)m]; ++j) {
-          wpad[(size_t)m * 16 + j] = wts[(size_t)off[(size_t)m] + j];
-        }
-      }
-      // Deal mel rows to the 8 waves so that (pass-2 work + mel work) is even:
-      // waves 0-3 own 4 butterflies, wave 4 three, waves 5-7 two.
-      const double bfly_cost = 150.0;
-      const double pre[8] = {4 * bfly_cost, 4 * bfly_cost, 4 * bfly_cost, 4 * bfly_cost,
-                             3 * bfly_cost, 2 * bfly_cost, 2 * bfly_cost, 2 * bfly_cost};
-      double total = 0.0;
-      std::vector<double> cost((size_t)d->n_mels);
-      for (int m = 0; m < d->n_mels; ++m) {
-        cost[(size_t)m] = 10.0 + 2.0 * len[(size_t)m];
-        total += cost[(size_t)m];
-      }
-      for (double c : pre) total += c;
-      const double target = total / 8.0;
-      std::vector<int> mpart(9, d->n_mels);
-      mpart[0] = 0;
-      int m = 0;
-      for (int w = 0; w < 8; ++w) {
-        double acc = pre[w];
-        mpart[(size_t)w] = m;
-        while (m < d->n_mels && (w == 7 || acc + 0.5 * cost[(size_t)m] <= target)) {
-          acc += cost[(size_t)m];
-          ++m;
-        }
-      }
-      mpart[8] = d->n_mels;
-      if ((rc = upload(&p->d_tw2, tw2)) != MIA_OK) return fail(rc);
-      if ((rc = upload(&p->d_tws, tws)) != MIA_OK) return fail(rc);
-      if ((rc = upload(&p->d_wpad, wpad)) != MIA_OK) return fail(rc);
-      if ((rc = upload(&p->d_mpart, mpart)) != MIA_OK) return fail(rc);
+    if (N == 400 && d->hop_length == 160 && d->power == 2.0f) {
+      rc = build_w400_tables(p, d->mel_basis, d->n_mels, bins);
+      if (rc != MIA_OK) return fail(rc);
     }
   }
   if (d->n_mfcc > 0) {
@@ -466,8 +551,8 @@ extern "C" size_t mia_mel_workspace_bytes(const mia_plan* plan, int64_t B, int64
 
 // The lane-per-frame kernel when the plan has its tables, else the generic one.
 static int forward_mel_dispatch(const mia_plan* plan, const FwdParams& p, hipStream_t s) {
-  if (plan->d_tw2 != nullptr) {
-    W400Tables tb{plan->d_tw2, plan->d_tws, plan->d_wpad, plan->d_mpart};
+  if (plan->d_sweep_meta != nullptr) {
+    W400Tables tb{plan->d_tw2, plan->d_tws, plan->d_sweep_meta, plan->d_sweep_w};
     return launch_logmel400(p, tb, s);
   }
   return launch_forward(plan, p, 1, s);
@@ -511,6 +596,7 @@ static int mel_forward(const mia_plan* plan, const float* y, int64_t B, int64_t 
     p.clip_max_key = max_keys;
     p.clip_min_key = min_keys;
   }
+  { const char* e = getenv("MIA_DBG"); p.dbg = e ? atoi(e) : 0; }
   rc = forward_mel_dispatch(plan, p, s);
   if (rc != MIA_OK) return rc;
   if (clamp && B > 0) {

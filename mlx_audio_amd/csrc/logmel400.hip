@@ -1,6 +1,7 @@
 // Fused mel front-end for n_fft = 400, hop = 160 (Whisper's framing):
-// pad + frame + window + 400-point real FFT + power + mel band projection +
-// log epilogue in one kernel, 64 frames of one clip per 512-thread workgroup.
+// pad + frame + window + 400-point real FFT + |X|^2 + mel band projection +
+// log epilogue in one persistent kernel; a 512-thread workgroup walks a run of
+// 64-frame tiles.
 //
 // Mapping.  LANE = frame, WAVE = role inside the FFT.  The 200-point complex
 // transform of z[n] = x[2n] + i x[2n+1] is split 8 x 25:
@@ -13,10 +14,20 @@
 // is a scalar or an instruction immediate, all 64 lanes work, and with odd /
 // 2-mod-4 row strides every LDS access is bank-conflict free.
 //
+// Mel stage.  Each bin k of a triangular filterbank feeds at most two
+// filters: the rising edge of filter s(k) and the falling edge of filter
+// s(k)-1.  Every wave owns a run of filters and sweeps the bins of those
+// filters once: two FMAs per bin, one emit (log, store, running max/min) per
+// filter.  The per-bin weights live in two VGPRs (lane i = i-th bin of the
+// wave) and are broadcast with v_readlane; the control (when a filter is
+// complete) is a 2-bit-per-bin scalar mask.
+//
 // LDS (one 53.8 KB buffer, reused three times per tile, 2 workgroups per CU):
 //   span : the tile's 10480 samples, rows of 160 samples at stride 162 dwords
 //   ex   : pass-1 -> pass-2 exchange, per frame 8 roles x 13 complex, stride 210
 //   P    : power spectrum, bin-major [201][64]
+// The next tile's samples are prefetched into registers while the current
+// tile computes.
 #include "fft_engine.h"
 #include "mia_internal.h"
 
@@ -25,12 +36,13 @@ namespace mia {
 namespace w400 {
 constexpr int N = 400, M = 200, HOP = 160, FT = 64, WG = 512;
 constexpr int SPAN = (FT - 1) * HOP + N;  // 10480 samples per tile
+constexpr int SPAN4 = SPAN / 4;           // 2620 float4
+constexpr int NPRE = (SPAN4 + WG - 1) / WG;  // 6 float4 per thread
 constexpr int RS = 162;                   // span row stride (dwords)
 constexpr int ES = 210;                   // exchange stride per frame (dwords)
-constexpr int LDS_DWORDS = FT * ES;       // 13440 >= 66*162 and >= 201*64
+constexpr int LDS_DWORDS = FT * ES;       // 13440 >= 66*162 and >= 201*64 (+7 rows slack)
 static_assert(LDS_DWORDS >= ((SPAN + HOP - 1) / HOP) * RS, "span fits");
-static_assert(LDS_DWORDS >= (M + 1) * FT, "power tile fits");
-constexpr int MAXLEN = 16;                // padded filter row length
+static_assert(LDS_DWORDS >= (M + 1 + 7) * FT, "power tile (+ read slack) fits");
 }  // namespace w400
 
 // Butterflies of pass 2 owned by each wave: a0 (+ partner 25-a0), optional a1
@@ -50,205 +62,324 @@ __device__ __forceinline__ void split_power(float2 U, float2 V, float2 w, float&
   pmk = 0.25f * (bx * bx + by * by);
 }
 
-__device__ __forceinline__ float apply_power(float pw, int mode, float power) {
-  if (mode == 1) return sqrtf(pw);
-  if (mode == 2) return powf(sqrtf(pw), power);
-  return pw;
+__device__ __forceinline__ float readlane_f(float v, int l) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
 }
 
-__global__ __launch_bounds__(w400::WG, 4) void logmel400_kernel(FwdParams p, W400Tables tb) {
+__device__ unsigned long long* g_dbgbuf = nullptr;
+#ifdef MIA_W400_STAMPS
+#define STAMP(i)                                                                          \
+  if ((p.dbg & 8) && g_dbgbuf && blockIdx.x == 77 && (threadIdx.x & 63) == 0 && it < 4)    \
+    g_dbgbuf[(it * 8 + (threadIdx.x >> 6)) * 16 + (i)] = __builtin_readcyclecounter();
+#else
+#define STAMP(i)
+#endif
+
+template <int EPI>
+__global__ __launch_bounds__(w400::WG, 4) void logmel400_kernel(
+    FwdParams p, const float* __restrict__ g_y, const float* __restrict__ g_win,
+    const float2* __restrict__ g_tw2, const float2* __restrict__ g_tws,
+    const int* __restrict__ g_meta, const float* __restrict__ g_sw, float* __restrict__ g_out,
+    int* __restrict__ g_maxkey, int* __restrict__ g_minkey) {
+  // Every table and the input come in as __restrict__ kernel arguments so that
+  // their wave-uniform loads are scalar (s_load) loads; through a struct member
+  // the compiler must assume they alias the output and falls back to vector loads.
   using namespace w400;
   __shared__ __attribute__((aligned(16))) float lds[LDS_DWORDS];
-  __shared__ float red[2][8];
 
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int t = __builtin_amdgcn_readfirstlane(tid >> 6);  // role
-  const long long b = blockIdx.x / p.tiles;
-  const int tile = blockIdx.x % p.tiles;
-  const long long f0 = (long long)tile * FT;
-  const float* __restrict__ yb = p.y + b * p.T;
-  const long long s_begin = f0 * HOP - p.pad;
+  const int tid0 = threadIdx.x;
+  const int lane0 = tid0 & 63;
+  const int t = __builtin_amdgcn_readfirstlane(tid0 >> 6);  // role
+  const int total = (int)(p.B * p.tiles);  // launcher guarantees < 2^31
+  const int first = (int)blockIdx.x * p.tiles_per_wg;
+  const int last = min(first + p.tiles_per_wg, total);
+  if (first >= last) return;
 
-  // ---- stage the tile's samples: global -> LDS, rows of 160 at stride 162 ----
-  {
-    const bool interior = s_begin >= 0 && s_begin + SPAN <= p.T &&
-                          ((reinterpret_cast<uintptr_t>(yb + s_begin) & 15) == 0);
-    if (interior) {
-      const float4* __restrict__ src = reinterpret_cast<const float4*>(yb + s_begin);
-#pragma unroll
-      for (int i = 0; i < (SPAN / 4 + WG - 1) / WG; ++i) {
-        const int q = tid + i * WG;
-        if (q < SPAN / 4) {
-          const float4 v = src[q];
-          float2* dst = reinterpret_cast<float2*>(lds + RS * (q / 40) + 4 * (q % 40));
-          dst[0] = {v.x, v.y};
-          dst[1] = {v.z, v.w};
-        }
-      }
-    } else {
-      for (int s = tid; s < SPAN; s += WG) {
-        lds[RS * (s / HOP) + (s % HOP)] = fetch_sample_any(yb, p.T, s_begin + s, p.pad_mode);
-      }
-    }
-  }
-  __syncthreads();
-
-  // ---- pass 1: radix-25 over z[t + 8r] of this lane's frame --------------------
-  float2 y[25];
-  {
-    const float2* __restrict__ sp = reinterpret_cast<const float2*>(lds + RS * lane + 2 * t);
-    const float2* __restrict__ win2 = reinterpret_cast<const float2*>(p.win) + t;
-#pragma unroll
-    for (int r = 0; r < 25; ++r) {
-      const float2 x = sp[(16 * r + 2 * (r / 10)) / 2];
-      const float2 w = win2[8 * r];
-      y[r] = {x.x * w.x, x.y * w.y};
-    }
-    Dft<25>::run(y);
-  }
-  __syncthreads();  // all span reads done; the buffer becomes the exchange area
-
-  float2* __restrict__ ex = reinterpret_cast<float2*>(lds);
-  const int exw = (ES * lane + 26 * t) / 2;  // this thread's 13 exchange slots
-  const int exr = (ES * lane) / 2;           // pass-2 reads: + 13*t' + c
+  // ---- per-wave constants -------------------------------------------------------
   const int a0k = kW400A0[t];
   const int a1k = kW400A1[t];
+  const int* __restrict__ meta = g_meta + 16 * t;
+  const int klo = meta[0], nseg = meta[1], m0 = meta[2];
+  // bins per segment, 4 bits each (segment sg -> word sg/8)
+  const unsigned cw0 = (unsigned)meta[4], cw1 = (unsigned)meta[5], cw2 = (unsigned)meta[6];
+  const unsigned cw3 = (unsigned)meta[7], cw4 = (unsigned)meta[8];
+  const float vwf = g_sw[(2 * t + 0) * 64 + lane0];  // falling-edge weight of bin klo+lane
+  const float vwr = g_sw[(2 * t + 1) * 64 + lane0];  // rising-edge weight
 
-  // phase A: outputs k1 = 0..12
-#pragma unroll
-  for (int c = 0; c < 13; ++c) ex[exw + c] = y[c];
-  __syncthreads();
-  float2 a0[8], a1[8];
-#pragma unroll
-  for (int q = 0; q < 8; ++q) a0[q] = ex[exr + 13 * q + a0k];
-  if (a1k >= 0) {
-#pragma unroll
-    for (int q = 0; q < 8; ++q) a1[q] = ex[exr + 13 * q + a1k];
-  }
-  __syncthreads();
-  // phase B: outputs k1 = 13..24 at slot k1 - 13
-#pragma unroll
-  for (int c = 0; c < 12; ++c) ex[exw + c] = y[13 + c];
-  __syncthreads();
-  float2 b0[8], b1[8];
-#pragma unroll
-  for (int q = 0; q < 8; ++q) b0[q] = ex[exr + 13 * q + (12 - a0k)];
-  if (a1k > 0) {
-#pragma unroll
-    for (int q = 0; q < 8; ++q) b1[q] = ex[exr + 13 * q + (12 - a1k)];
-  }
-  __syncthreads();  // exchange reads done; the buffer becomes the power tile
+  // ---- span prefetch: the tile's samples -> registers -------------------------------
+  int tid = tid0, lane = lane0;
+  int cur_b = first / p.tiles;             // clip and tile-in-clip of the current tile,
+  int cur_tile = first - cur_b * p.tiles;  // advanced incrementally
 
-  // ---- pass 2 + split + power, written bin-major: P[k][frame] ---------------------
-  float* __restrict__ P = lds;
-  auto twiddle8 = [&](float2 (&v)[8], int k1) {
-    const float2* __restrict__ w = tb.tw2 + 8 * k1;
-#pragma unroll
-    for (int q = 1; q < 8; ++q) v[q] = cmul(v[q], w[q]);
-    Dft<8>::run(v);
-  };
-  auto do_pair = [&](float2 (&a)[8], float2 (&bb)[8], int k1) {
-    twiddle8(a, k1);
-    twiddle8(bb, 25 - k1);
-    const float2* __restrict__ ws = tb.tws + 8 * k1;
-    float* __restrict__ pa = P + FT * k1 + lane;         // bins k1 + 25*k2
-    float* __restrict__ pb = P + FT * (25 - k1) + lane;  // bins (25-k1) + 25*k2
-#pragma unroll
-    for (int k2 = 0; k2 < 8; ++k2) {
-      float pk, pmk;
-      split_power(a[k2], bb[7 - k2], ws[k2], pk, pmk);
-      pa[FT * 25 * k2] = apply_power(pk, p.power_mode, p.power);
-      pb[FT * 25 * (7 - k2)] = apply_power(pmk, p.power_mode, p.power);
+  int it = 0;
+  for (int idx = first; idx < last; ++idx, ++it) {
+    const long long b = cur_b;
+    const int tile = cur_tile;
+    if (++cur_tile == p.tiles) {
+      cur_tile = 0;
+      ++cur_b;
     }
-  };
-  do_pair(a0, b0, a0k);
-  if (a1k > 0) {
-    do_pair(a1, b1, a1k);
-  } else if (a1k == 0) {
-    // butterfly 0: bins 25*k2, paired inside the butterfly (k2 <-> 8-k2)
-    Dft<8>::run(a1);
-    const float2* __restrict__ ws = tb.tws;
-    float* __restrict__ pz = P + lane;
-    float pk, pmk;
-    split_power(a1[0], a1[0], ws[0], pk, pmk);
-    pz[0] = apply_power(pk, p.power_mode, p.power);
-    pz[FT * 200] = apply_power(pmk, p.power_mode, p.power);
-#pragma unroll
-    for (int k2 = 1; k2 < 4; ++k2) {
-      split_power(a1[k2], a1[8 - k2], ws[k2], pk, pmk);
-      pz[FT * 25 * k2] = apply_power(pk, p.power_mode, p.power);
-      pz[FT * 25 * (8 - k2)] = apply_power(pmk, p.power_mode, p.power);
-    }
-    pz[FT * 100] = apply_power(a1[4].x * a1[4].x + a1[4].y * a1[4].y, p.power_mode, p.power);
-  }
-  __syncthreads();
+    const long long f0 = (long long)tile * FT;
+    // Re-derive the lane-dependent addresses every tile instead of keeping a
+    // few dozen loop-invariant VGPRs alive across the whole loop body.
+    tid = tid0;
+    asm volatile("" : "+v"(tid)::"memory");  // also keeps this tile's loads below this point
+    lane = tid & 63;
+    STAMP(0)
 
-  // ---- mel band projection + log epilogue: wave t owns mels [m0, m1) ---------------
-  const long long f = f0 + lane;
-  const bool valid = f < p.F;
-  const int m0 = tb.mpart[t], m1 = tb.mpart[t + 1];
-  float vmax = -INFINITY, vmin = INFINITY;
-  float* __restrict__ orow = p.mout + (b * p.n_mels) * p.F + f;
-  for (int m = m0; m < m1; ++m) {
-    const int lo = p.row_lo[m], len = p.row_len[m];
-    const float* __restrict__ w = tb.wpad + MAXLEN * m;
-    const float* __restrict__ pr = P + FT * lo + lane;
-    float acc = 0.0f;
+    // ---- stage the tile's samples: global -> LDS, rows of 160 at stride 162 ---------
+    {
+      const float* __restrict__ yb = g_y + b * p.T;
+      const long long s_begin = f0 * HOP - p.pad;
+      // tiles wholly inside the clip (no padding, 16-byte aligned) take the
+      // vector path; the edge tiles of a clip a plain per-sample loop
+      const bool interior = s_begin >= 0 && s_begin + SPAN <= p.T &&
+                            ((reinterpret_cast<uintptr_t>(yb + s_begin) & 15) == 0);
+      if (p.dbg & 2) {
+        for (int s = tid; s < LDS_DWORDS; s += WG) lds[s] = 0.001f * (s & 63);
+      } else if (interior) {
+        const float4* __restrict__ src = reinterpret_cast<const float4*>(yb + s_begin);
+        float4 pre[NPRE];
 #pragma unroll
-    for (int j = 0; j < MAXLEN; ++j) {
-      if (j < len) acc = fmaf(w[j], pr[FT * j], acc);
-    }
-    float outv = acc;
-    if (p.epi == MIA_EPI_WHISPER) {
-      const float yv = acc <= 1e-10f ? -10.0f : __log10f(acc);
-      vmax = fmaxf(vmax, yv);
-      outv = (yv + 4.0f) * 0.25f;
-      vmin = fminf(vmin, outv);
-    } else if (p.epi == MIA_EPI_DB) {
-      outv = acc <= p.amin ? p.db_floor : p.coef * __log10f(acc * p.inv_ref);
-      vmax = fmaxf(vmax, outv);
-      vmin = fminf(vmin, outv);
-    }
-    if (valid) orow[(long long)m * p.F] = outv;
-  }
-  if (p.epi != MIA_EPI_NONE && p.clip_max_key != nullptr) {
-    if (!valid) {
-      vmax = -INFINITY;
-      vmin = INFINITY;
-    }
+        for (int i = 0; i < NPRE; ++i) {
+          const int q = tid + i * WG;
+          pre[i] = src[q < SPAN4 ? q : SPAN4 - 1];
+        }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      vmax = fmaxf(vmax, __shfl_xor(vmax, off));
-      vmin = fminf(vmin, __shfl_xor(vmin, off));
-    }
-    if (lane == 0) {
-      red[0][t] = vmax;
-      red[1][t] = vmin;
-    }
-    __syncthreads();
-    if (tid == 0) {
-#pragma unroll
-      for (int w = 1; w < 8; ++w) {
-        vmax = fmaxf(vmax, red[0][w]);
-        vmin = fminf(vmin, red[1][w]);
+        for (int i = 0; i < NPRE; ++i) {
+          const int q = tid + i * WG;
+          if (q < SPAN4) {
+            float2* dst = reinterpret_cast<float2*>(lds + RS * (q / 40) + 4 * (q % 40));
+            dst[0] = {pre[i].x, pre[i].y};
+            dst[1] = {pre[i].z, pre[i].w};
+          }
+        }
+      } else {
+#pragma unroll 1
+        for (int s = tid; s < SPAN; s += WG) {
+          lds[RS * (s / HOP) + (s % HOP)] = fetch_sample(yb, p.T, s_begin + s, p.pad_mode);
+        }
       }
-      atomicMax(p.clip_max_key + b, float_to_key(vmax));
-      atomicMin(p.clip_min_key + b, float_to_key(vmin));
     }
+    STAMP(1)
+    __syncthreads();
+    STAMP(2)
+
+    // ---- pass 1: radix-25 over z[t + 8r] of this lane's frame --------------------------
+    float2 y[25];
+    {
+      const float2* __restrict__ sp = reinterpret_cast<const float2*>(lds + RS * lane + 2 * t);
+      const float2* __restrict__ win2 = reinterpret_cast<const float2*>(g_win) + t;
+#pragma unroll
+      for (int r = 0; r < 25; ++r) {
+        const float2 x = sp[(16 * r + 2 * (r / 10)) / 2];
+        const float2 w = win2[8 * r];
+        y[r] = {x.x * w.x, x.y * w.y};
+      }
+      Dft<25>::run(y);
+    }
+    STAMP(3)
+    __syncthreads();  // all span reads done; the buffer becomes the exchange area
+    STAMP(4)
+
+    float2* __restrict__ ex = reinterpret_cast<float2*>(lds);
+    const int exw = (ES * lane + 26 * t) / 2;  // this thread's 13 exchange slots
+    const int exr = (ES * lane) / 2;           // pass-2 reads: + 13*t' + c
+
+    // phase A: outputs k1 = 0..12
+#pragma unroll
+    for (int c = 0; c < 13; ++c) ex[exw + c] = y[c];
+    STAMP(5)
+    __syncthreads();
+    STAMP(6)
+    float2 a0[8], a1[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) a0[q] = ex[exr + 13 * q + a0k];
+    if (a1k >= 0) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) a1[q] = ex[exr + 13 * q + a1k];
+    }
+    STAMP(7)
+    __syncthreads();
+    STAMP(8)
+    // phase B: outputs k1 = 13..24 at slot k1 - 13
+#pragma unroll
+    for (int c = 0; c < 12; ++c) ex[exw + c] = y[13 + c];
+    STAMP(9)
+    __syncthreads();
+    STAMP(10)
+    // ---- pass 2 + split + power ------------------------------------------------------
+    // The partner butterflies arrive with phase B: finish one pair at a time so
+    // that only one pair's inputs are live, keep the 16 + 16 power values in
+    // registers, and write them once every wave has read its exchange slots.
+    auto twiddle8 = [&](float2 (&v)[8], int k1) {
+      const float2* __restrict__ w = g_tw2 + 8 * k1;
+#pragma unroll
+      for (int q = 1; q < 8; ++q) v[q] = cmul(v[q], w[q]);
+      Dft<8>::run(v);
+    };
+    auto do_pair = [&](float2 (&a)[8], int k1, float (&pk)[8], float (&pm)[8]) {
+      float2 bb[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) bb[q] = ex[exr + 13 * q + (12 - k1)];
+      twiddle8(a, k1);
+      twiddle8(bb, 25 - k1);
+      const float2* __restrict__ ws = g_tws + 8 * k1;
+#pragma unroll
+      for (int k2 = 0; k2 < 8; ++k2) split_power(a[k2], bb[7 - k2], ws[k2], pk[k2], pm[7 - k2]);
+    };
+    float pk0[8], pm0[8], pk1[8], pm1[8];
+    do_pair(a0, a0k, pk0, pm0);
+    if (a1k > 0) {
+      do_pair(a1, a1k, pk1, pm1);
+    } else if (a1k == 0) {
+      // butterfly 0: bins 25*k2, paired inside the butterfly (k2 <-> 8-k2);
+      // pk1[k2] = bin 25*k2 (k2 = 0..4), pm1[k2] = bin 200 - 25*k2 (k2 = 0..3)
+      Dft<8>::run(a1);
+      const float2* __restrict__ ws = g_tws;
+      split_power(a1[0], a1[0], ws[0], pk1[0], pm1[0]);
+#pragma unroll
+      for (int k2 = 1; k2 < 4; ++k2) split_power(a1[k2], a1[8 - k2], ws[k2], pk1[k2], pm1[k2]);
+      pk1[4] = a1[4].x * a1[4].x + a1[4].y * a1[4].y;
+    }
+    STAMP(11)
+    __syncthreads();  // exchange reads done; the buffer becomes the power tile
+    STAMP(12)
+
+    float* __restrict__ P = lds;  // bin-major: P[k][frame]
+    {
+      float* __restrict__ pa = P + FT * a0k + lane;         // bins a0k + 25*k2
+      float* __restrict__ pb = P + FT * (25 - a0k) + lane;  // bins (25-a0k) + 25*k2
+#pragma unroll
+      for (int k2 = 0; k2 < 8; ++k2) {
+        pa[FT * 25 * k2] = pk0[k2];
+        pb[FT * 25 * k2] = pm0[k2];
+      }
+    }
+    if (a1k > 0) {
+      float* __restrict__ pa = P + FT * a1k + lane;
+      float* __restrict__ pb = P + FT * (25 - a1k) + lane;
+#pragma unroll
+      for (int k2 = 0; k2 < 8; ++k2) {
+        pa[FT * 25 * k2] = pk1[k2];
+        pb[FT * 25 * k2] = pm1[k2];
+      }
+    } else if (a1k == 0) {
+      float* __restrict__ pz = P + lane;
+#pragma unroll
+      for (int k2 = 0; k2 < 5; ++k2) pz[FT * 25 * k2] = pk1[k2];
+#pragma unroll
+      for (int k2 = 0; k2 < 4; ++k2) pz[FT * (200 - 25 * k2)] = pm1[k2];
+    }
+    STAMP(13)
+    __syncthreads();
+    STAMP(14)
+
+    // ---- mel sweep + log epilogue ---------------------------------------------------------
+    if (!(p.dbg & 1)) {
+      const long long f = f0 + lane;
+      const bool valid = (f < p.F) && !(p.dbg & 4);
+      float* __restrict__ optr = g_out + ((b * p.n_mels + m0) * p.F + f);
+      const float* __restrict__ pr = P + FT * klo + lane;
+      float prevR = 0.0f;
+      float vmax = -INFINITY, vmin = INFINITY;
+      int bin = 0;  // bins consumed so far (uniform)
+      for (int sg = 0; sg < nseg; ++sg) {
+        const unsigned cw = sg < 8 ? cw0 : (sg < 16 ? cw1 : (sg < 24 ? cw2 : (sg < 32 ? cw3 : cw4)));
+        const int n = (cw >> (4 * (sg & 7))) & 15;
+        float accR = 0.0f, accF = 0.0f;
+        const float* __restrict__ q = pr + FT * bin;
+        // straight-line per bin count, so all LDS reads of a segment are in flight together
+        switch (n) {
+#define MIA_CASE(NB)                                              \
+  case NB: {                                                      \
+    float pv[NB];                                                 \
+    _Pragma("unroll") for (int j = 0; j < NB; ++j) pv[j] = q[FT * j]; \
+    _Pragma("unroll") for (int j = 0; j < NB; ++j) {              \
+      accF = fmaf(readlane_f(vwf, bin + j), pv[j], accF);         \
+      accR = fmaf(readlane_f(vwr, bin + j), pv[j], accR);         \
+    }                                                             \
+  } break;
+          MIA_CASE(1) MIA_CASE(2) MIA_CASE(3) MIA_CASE(4) MIA_CASE(5) MIA_CASE(6) MIA_CASE(7)
+          MIA_CASE(8) MIA_CASE(9) MIA_CASE(10) MIA_CASE(11) MIA_CASE(12) MIA_CASE(13)
+          MIA_CASE(14) MIA_CASE(15)
+#undef MIA_CASE
+          default: break;
+        }
+        bin += n;
+        if (sg > 0) {  // filter m0 + sg - 1 is complete: rising part + falling part
+          const float acc = prevR + accF;
+          float outv = acc;
+          if (EPI == MIA_EPI_WHISPER) {
+            const float yv = acc <= 1e-10f ? -10.0f : __log10f(acc);
+            vmax = fmaxf(vmax, yv);
+            outv = (yv + 4.0f) * 0.25f;
+            vmin = fminf(vmin, outv);
+          } else if (EPI == MIA_EPI_DB) {
+            outv = acc <= p.amin ? p.db_floor : p.coef * __log10f(acc * p.inv_ref);
+            vmax = fmaxf(vmax, outv);
+            vmin = fminf(vmin, outv);
+          }
+          if (valid) *optr = outv;
+          optr += p.F;
+        }
+        prevR = accR;
+      }
+
+      if (EPI != MIA_EPI_NONE && g_maxkey != nullptr) {
+        if (!(f < p.F)) {
+          vmax = -INFINITY;
+          vmin = INFINITY;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+          vmax = fmaxf(vmax, __shfl_xor(vmax, off));
+          vmin = fminf(vmin, __shfl_xor(vmin, off));
+        }
+        if (lane == 0) {
+          atomicMax(g_maxkey + b, float_to_key(vmax));
+          atomicMin(g_minkey + b, float_to_key(vmin));
+        }
+      }
+    }
+    STAMP(15)
+    __syncthreads();  // power tile reads done before the next tile is staged
   }
+}
+
+extern "C" void mia_debug_set_buffer(void* ptr) {
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dbgbuf), &ptr, sizeof(ptr));
 }
 
 int launch_logmel400(const FwdParams& p0, const W400Tables& tb, hipStream_t s) {
   FwdParams p = p0;
   p.tiles = (int)((p.F + w400::FT - 1) / w400::FT);
-  const long long blocks = p.B * p.tiles;
-  if (blocks <= 0) return MIA_OK;
-  if (blocks > 0x7fffffffLL) {
-    set_error("grid too large: %lld workgroups", blocks);
-    return MIA_ERR_INVALID;
+  const long long total = p.B * p.tiles;
+  if (total <= 0) return MIA_OK;
+  // Persistent grid: 2 workgroups per CU, each walking a contiguous run of
+  // tiles (consecutive tiles of a clip share cache lines of the output rows,
+  // so one workgroup - one L2 - writes both halves of each line).
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   }
-  hipLaunchKernelGGL(logmel400_kernel, dim3((unsigned)blocks), dim3(w400::WG), 0, s, p, tb);
+  long long grid = 2LL * cus;
+  if (grid > total) grid = total;
+  p.tiles_per_wg = (int)((total + grid - 1) / grid);
+  grid = (total + p.tiles_per_wg - 1) / p.tiles_per_wg;
+  if (p.epi == MIA_EPI_WHISPER) {
+    hipLaunchKernelGGL(logmel400_kernel<MIA_EPI_WHISPER>, dim3((unsigned)grid), dim3(w400::WG), 0,
+                       s, p, p.y, p.win, tb.tw2, tb.tws, tb.sweep_meta, tb.sweep_w, p.mout,
+                       p.clip_max_key, p.clip_min_key);
+  } else if (p.epi == MIA_EPI_DB) {
+    hipLaunchKernelGGL(logmel400_kernel<MIA_EPI_DB>, dim3((unsigned)grid), dim3(w400::WG), 0, s,
+                       p, p.y, p.win, tb.tw2, tb.tws, tb.sweep_meta, tb.sweep_w, p.mout,
+                       p.clip_max_key, p.clip_min_key);
+  } else {
+    hipLaunchKernelGGL(logmel400_kernel<MIA_EPI_NONE>, dim3((unsigned)grid), dim3(w400::WG), 0, s,
+                       p, p.y, p.win, tb.tw2, tb.tws, tb.sweep_meta, tb.sweep_w, p.mout,
+                       p.clip_max_key, p.clip_min_key);
+  }
   MIA_CHECK_HIP(hipGetLastError());
   return MIA_OK;
 }

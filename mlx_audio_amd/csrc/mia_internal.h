@@ -81,8 +81,8 @@ struct mia_plan {
   // extra tables of the n_fft = 400 / hop = 160 kernel (null when not applicable)
   float2* d_tw2 = nullptr;       // [25][8]  exp(-2 pi i t k1 / 200)
   float2* d_tws = nullptr;       // [13][8]  exp(-2 pi i (k1 + 25 k2) / 400)
-  float* d_wpad = nullptr;       // [n_mels][16] filter rows, zero padded
-  int* d_mpart = nullptr;        // [9] mel rows owned by each of the 8 waves
+  int* d_sweep_meta = nullptr;   // [8][16] per-wave sweep program (see logmel400.hip)
+  float* d_sweep_w = nullptr;    // [8][2][64] falling / rising weight of the wave's i-th bin
 };
 
 namespace mia {
@@ -90,7 +90,7 @@ namespace mia {
 struct FwdParams {
   const float* y;
   long long B, T, F;
-  int hop, pad, pad_mode, tiles;
+  int hop, pad, pad_mode, tiles, tiles_per_wg;
   const float* win;
   const float2* tw;
   float scale;
@@ -109,13 +109,14 @@ struct FwdParams {
   float db_floor;      // coef*log10(amin/max(ref,amin)), the value of clamped inputs
   int* clip_max_key;   // B (+1) keys of the per-clip maximum, or nullptr
   int* clip_min_key;   // B keys of the per-clip minimum of the stored values
+  int dbg;
 };
 
 struct W400Tables {
   const float2* tw2;
   const float2* tws;
-  const float* wpad;
-  const int* mpart;
+  const int* sweep_meta;
+  const float* sweep_w;
 };
 
 struct InvParams {
