@@ -80,6 +80,26 @@ def make_workload(name: str, clips: int, device, seed: int):
     raise SystemExit(f"unknown workload {name}")
 
 
+KERNEL_OF = {
+    "whisper128": "logmel400_kernel (fused pad+frame+window+rFFT-400+128-mel+log10)",
+    "clap64": "fwd_kernel<1024, mel> (fused pad+frame+window+rFFT+mel+dB)",
+    "mfcc40": "fwd_kernel<2048, mel> (fused rFFT+mel+dB) followed by dct2_kernel",
+    "htdemucs": "fwd_kernel<4096> then inv_kernel<4096> + ola_kernel",
+}
+
+
+def measured_traffic(workload: str, clips: int):
+    """HBM bytes per step from the committed PMC passes (FETCH_SIZE doubled as
+    gfx950 needs, plus WRITE_SIZE), or None if that workload/size has no pass."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        table = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    entry = table.get(f"{workload}:{clips}")
+    return None if entry is None else entry.get("hbm_bytes_per_step")
+
+
 def cpu_baseline(budget_s: float = 12.0) -> dict:
     """The CPU oracle (NumPy float32 pocketfft + sgemm, the reference's op
     sequence) on the reference's CPU-runnable case: Whisper 80-mel log-mel of
@@ -136,6 +156,8 @@ def main() -> None:
 
     import torch
 
+    from mlx_audio_amd.sharding import max_over_ranks
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -180,10 +202,7 @@ def main() -> None:
     elapsed = time.perf_counter() - t0
     dev_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
     del out
-    if dist is not None:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(elapsed, device)
 
     if rank == 0:
         value = n_gpus * units * args.steps / elapsed
@@ -209,10 +228,10 @@ def main() -> None:
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
-                "kernel": "fwd_kernel (fused pad+frame+window+rFFT+mel+log), timed with "
-                          "stream events around each step (includes the memset and the "
-                          "floor pass launched with it)",
+                "traffic": measured_traffic(args.workload, clips),
+                "kernel": KERNEL_OF.get(args.workload, "fwd_kernel") + ", timed with stream "
+                          "events around each step (so the key memset and the floor pass "
+                          "launched with it are inside the measured time)",
                 "algorithmic_bytes_per_step": abytes,
                 "device_ms_per_step": dev_ms,
             },

@@ -91,6 +91,13 @@ _load_error: str | None = None
 def _load():
     global HAS_HIP_EXT, _lib, _load_error
     try:
+        # One HIP runtime per process: PyTorch-ROCm bundles its own
+        # libamdhip64.so.7 and the tensors and streams handed to the kernels
+        # belong to it.  Importing torch first makes the dynamic loader resolve
+        # libmia_hip.so's NEEDED libamdhip64.so.7 to that already-loaded copy;
+        # the other order would put a second runtime (ROCm's) in the process.
+        import torch  # noqa: F401
+
         lib = ctypes.CDLL(LIB_PATH)
         for name, (restype, argtypes) in SIGNATURES.items():
             fn = getattr(lib, name)

@@ -88,7 +88,7 @@ int mia_version(void) { return 100; }
 
 int mia_generate_window(const char* type, int length, int periodic, float* out) {
   MIA_REQUIRE(type != nullptr && out != nullptr, "null argument");
-  MIA_REQUIRE(length >= 0, "Window length must be non-negative, got %d", length);
+  MIA_REQUIRE(length > 0, "Window length must be positive, got %d", length);
   const int kind = window_kind(type);
   MIA_REQUIRE(kind >= 0,
               "Unknown window type: '%s'. Supported: bartlett, blackman, boxcar, hamming, "

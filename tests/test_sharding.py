@@ -1,0 +1,77 @@
+"""world_size-2 check of the multi-GPU plumbing on the CPU (gloo).
+
+The data path has no collective: each rank processes its own block of clips.
+Here the per-rank compute is the CPU oracle (the HIP path needs a GPU); what
+is under test is the partition, the MAX reduction used for timing and the
+optional feature gather — the same helpers bench.py uses under RCCL.
+"""
+
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from mlx_audio_amd.sharding import clip_shard, gather_features, max_over_ranks
+
+
+def test_clip_shard_partitions_exactly():
+    for n in (0, 1, 5, 8, 1023, 1024):
+        for world in (1, 2, 3, 8):
+            blocks = [clip_shard(n, r, world) for r in range(world)]
+            assert blocks[0][0] == 0 and blocks[-1][1] == n
+            for (a0, a1), (b0, b1) in zip(blocks, blocks[1:]):
+                assert a1 == b0 and a0 <= a1 and b0 <= b1
+            assert max(b - a for a, b in blocks) == -(-n // world)
+    with pytest.raises(ValueError):
+        clip_shard(4, 2, 2)
+    with pytest.raises(ValueError):
+        clip_shard(-1, 0, 1)
+
+
+def test_single_process_helpers_are_identity():
+    t = torch.arange(6.0).reshape(3, 2)
+    assert gather_features(t, 3) is t
+    assert max_over_ranks(1.25) == 1.25
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank: int, world: int, port: int, n_clips: int, out_path: str):
+    import oracle.spectral as o
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(99)  # every rank draws the same full batch
+        clips = rng.standard_normal((n_clips, 8000)).astype(np.float32)
+        a, b = clip_shard(n_clips, rank, world)
+        # per-clip maximum: one oracle call per clip, as the reference's callers do
+        mine = [o.compute_log_mel_spectrogram(clips[i], n_mels=80) for i in range(a, b)]
+        local = torch.from_numpy(np.stack(mine)) if mine else torch.empty((0, 80, 51))
+        slowest = max_over_ranks(1.0 + rank)
+        assert slowest == float(world)
+        full = gather_features(local, n_clips, dst=0)
+        if rank == 0:
+            want = np.stack([o.compute_log_mel_spectrogram(c, n_mels=80) for c in clips])
+            np.testing.assert_array_equal(full.numpy(), want)
+            open(out_path, "w").write("ok")
+        else:
+            assert full is None
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_clips", [4, 5])
+def test_two_ranks_shard_and_gather(tmp_path, n_clips):
+    out = tmp_path / "ok.txt"
+    mp.spawn(_worker, args=(2, _free_port(), n_clips, str(out)), nprocs=2, join=True)
+    assert out.read_text() == "ok"
