@@ -241,18 +241,14 @@ static int build_w400_tables(mia_plan* p, const float* basis, int n_mels, int bi
       if (v != basis[(size_t)m * bins + k]) return MIA_OK;
     }
   }
-  // Deal filters to the 8 waves so that pass-2 work + sweep work is even
-  // (waves 0-3 own 4 butterflies, wave 4 three, waves 5-7 two); a wave may
-  // hold at most 64 bins.
-  const double bfly = 150.0, per_mel = 40.0, per_bin = 3.0;
-  const double pre[8] = {4 * bfly, 4 * bfly, 4 * bfly, 4 * bfly, 3 * bfly, 2 * bfly, 2 * bfly,
-                         2 * bfly};
+  // Per-segment bin runs.  Segment s holds the bins between the centres of
+  // filters s-1 and s; it may be empty (filters narrower than the bin spacing).
   std::vector<int> seg_count((size_t)n_mels + 1, 0), seg_first((size_t)n_mels + 1, -1);
   for (int k = 0; k < bins; ++k) {
     const int s = seg[(size_t)k];
     if (s > n_mels) return MIA_OK;
     if (seg_first[(size_t)s] < 0) seg_first[(size_t)s] = k;
-    if (++seg_count[(size_t)s] > 15) return MIA_OK;
+    ++seg_count[(size_t)s];
   }
   auto bins_of = [&](int m0, int m1, int& klo) {  // bins with m0 <= s(k) <= m1
     int lo = -1, n = 0;
@@ -263,19 +259,24 @@ static int build_w400_tables(mia_plan* p, const float* basis, int n_mels, int bi
     klo = lo < 0 ? 0 : lo;
     return n;
   };
-  // Smallest per-wave cost bound for which a greedy left-to-right deal fits all
-  // filters into 8 waves (<= 32 filters and <= 64 bins per wave).
+  // Deal contiguous runs of filters to the 8 waves with even sweep cost
+  // (about 2 instructions per bin, 7 per filter, 10 per 8-bin chunk): the
+  // smallest bound for which a greedy left-to-right deal places every filter.
+  constexpr int kMaxChunks = 13, kChunk = 8, kRec = 32;
+  auto cost = [&](int m0, int m1) {  // filters [m0, m1)
+    int klo = 0;
+    const int nb = bins_of(m0, m1, klo);
+    return 7.0 * (m1 - m0) + 2.0 * nb + 10.0 * ((nb + kChunk - 1) / kChunk);
+  };
   auto deal = [&](double bound, int* starts) {
     int m = 0;
     for (int w = 0; w < 8; ++w) {
       starts[w] = m;
-      int klo = 0;
-      while (m < n_mels && m - starts[w] < 32) {
-        const int nb = bins_of(starts[w], m + 1, klo);
-        if (nb > 64) break;
-        const double c = pre[w] + (m + 1 - starts[w]) * per_mel + nb * per_bin;
-        if (c > bound && m > starts[w]) break;
-        if (c > bound && pre[w] + per_mel + nb * per_bin > bound) break;
+      while (m < n_mels) {
+        int klo = 0;
+        if (bins_of(starts[w], m + 1, klo) > kMaxChunks * kChunk) break;
+        if (cost(starts[w], m + 1) > bound && m > starts[w]) break;
+        if (cost(starts[w], m + 1) > bound) break;
         ++m;
       }
     }
@@ -290,27 +291,54 @@ static int build_w400_tables(mia_plan* p, const float* basis, int n_mels, int bi
     if (deal(mid, starts)) hi_b = mid; else lo_b = mid;
   }
   deal(hi_b, starts);
+  // Per-wave sweep program.  The wave walks the bins of segments m0..m1 in
+  // chunks of 8; record c holds, for its 8 bins, the weight into the filter
+  // being completed (wA), the weight into the next filter (wB) and a control
+  // word with, per bin, the number of filters that are complete after it.
+  //   segment m0     : rising edge of m0          -> wA (the filter in progress)
+  //   segment m0+j   : falling edge of m0+j-1     -> wA, rising edge of m0+j -> wB
+  //   segment m1     : falling edge of m1-1       -> wA, nothing            -> wB
   std::vector<int> meta(8 * 16, 0);
-  std::vector<float> sw(8 * 2 * 64, 0.0f);
+  std::vector<float> sw((size_t)8 * kMaxChunks * kRec, 0.0f);
   for (int w = 0; w < 8; ++w) {
     const int m0 = starts[w];
-    const int m1 = starts[w + 1];  // wave owns filters [m0, m1) = segments m0..m1
-    int klo = 0;
+    const int m1 = starts[w + 1];
     int* mt = &meta[(size_t)w * 16];
     mt[2] = m0;
-    if (m1 == m0) continue;  // nseg = 0: nothing to do
+    if (m1 == m0) continue;  // no filters: nchunks = npre = 0
+    int klo = 0;
     const int nb = bins_of(m0, m1, klo);
     mt[0] = klo;
-    mt[1] = m1 - m0 + 1;
-    int i = 0;
+    mt[1] = (nb + kChunk - 1) / kChunk;
+    float* rec = &sw[(size_t)w * kMaxChunks * kRec];
+    int i = 0;        // bins emitted into the program so far
+    int pending = 0;  // filters complete before the next bin
+    int npre = 0;
     for (int s = m0; s <= m1; ++s) {
-      mt[4 + (s - m0) / 8] |= seg_count[(size_t)s] << (4 * ((s - m0) % 8));
       for (int j = 0; j < seg_count[(size_t)s]; ++j, ++i) {
         const int k = seg_first[(size_t)s] + j;
-        sw[(size_t)(2 * w + 0) * 64 + i] = wf[(size_t)k];
-        sw[(size_t)(2 * w + 1) * 64 + i] = wr[(size_t)k];
+        if (k != klo + i) return MIA_OK;
+        float* r = rec + (size_t)(i / kChunk) * kRec;
+        r[i % kChunk] = (s == m0) ? wr[(size_t)k] : wf[(size_t)k];
+        r[kChunk + i % kChunk] = (s == m0 || s == m1) ? 0.0f : wr[(size_t)k];
       }
+      // the end of segment s > m0 completes filter s-1
+      if (s > m0) {
+        if (i == 0) {
+          ++npre;
+        } else {
+          float* r = rec + (size_t)((i - 1) / kChunk) * kRec;
+          int ctrl;
+          std::memcpy(&ctrl, &r[2 * kChunk], sizeof(int));
+          const int sh = 4 * ((i - 1) % kChunk);
+          if (((ctrl >> sh) & 15) == 15) return MIA_OK;
+          ctrl += 1 << sh;
+          std::memcpy(&r[2 * kChunk], &ctrl, sizeof(int));
+        }
+      }
+      (void)pending;
     }
+    mt[3] = npre;
     if (i != nb) return MIA_OK;
   }
   std::vector<float2> tw2(25 * 8), tws(13 * 8);
@@ -580,6 +608,7 @@ static int mel_forward(const mia_plan* plan, const float* y, int64_t B, int64_t 
   p.inv_ref = 1.0f / fmaxf(ref, amin);
   p.coef = coef;
   p.db_floor = coef * log10f(amin / fmaxf(ref, amin));
+  p.db_floor_shift = coef * log10f(1.0f / fmaxf(ref, amin));
   const bool clamp = epilogue == MIA_EPI_WHISPER || (epilogue == MIA_EPI_DB && top_db >= 0.0f);
   int* max_keys = nullptr;
   int* min_keys = nullptr;

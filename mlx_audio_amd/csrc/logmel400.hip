@@ -40,9 +40,11 @@ constexpr int SPAN4 = SPAN / 4;           // 2620 float4
 constexpr int NPRE = (SPAN4 + WG - 1) / WG;  // 6 float4 per thread
 constexpr int RS = 162;                   // span row stride (dwords)
 constexpr int ES = 210;                   // exchange stride per frame (dwords)
-constexpr int LDS_DWORDS = FT * ES;       // 13440 >= 66*162 and >= 201*64 (+7 rows slack)
+constexpr int LDS_DWORDS = FT * ES;       // 13440 >= 66*162 and >= 201*64 (+8 rows slack)
+constexpr int MEL_MAXC = 13;              // mel sweep: chunks of 8 bins per wave, at most
+constexpr int MEL_REC = 32;               // dwords per chunk record: wA[8], wB[8], ctrl, pad
 static_assert(LDS_DWORDS >= ((SPAN + HOP - 1) / HOP) * RS, "span fits");
-static_assert(LDS_DWORDS >= (M + 1 + 7) * FT, "power tile (+ read slack) fits");
+static_assert(LDS_DWORDS >= (M + 1 + 8) * FT, "power tile (+ read slack) fits");
 }  // namespace w400
 
 // Butterflies of pass 2 owned by each wave: a0 (+ partner 25-a0), optional a1
@@ -85,7 +87,11 @@ __global__ __launch_bounds__(w400::WG, 4) void logmel400_kernel(
   // their wave-uniform loads are scalar (s_load) loads; through a struct member
   // the compiler must assume they alias the output and falls back to vector loads.
   using namespace w400;
+#ifdef MIA_W400_LDS_PAD
+  __shared__ __attribute__((aligned(16))) float lds[LDS_DWORDS + MIA_W400_LDS_PAD];
+#else
   __shared__ __attribute__((aligned(16))) float lds[LDS_DWORDS];
+#endif
 
   const int tid0 = threadIdx.x;
   const int lane0 = tid0 & 63;
@@ -99,12 +105,10 @@ __global__ __launch_bounds__(w400::WG, 4) void logmel400_kernel(
   const int a0k = kW400A0[t];
   const int a1k = kW400A1[t];
   const int* __restrict__ meta = g_meta + 16 * t;
-  const int klo = meta[0], nseg = meta[1], m0 = meta[2];
-  // bins per segment, 4 bits each (segment sg -> word sg/8)
-  const unsigned cw0 = (unsigned)meta[4], cw1 = (unsigned)meta[5], cw2 = (unsigned)meta[6];
-  const unsigned cw3 = (unsigned)meta[7], cw4 = (unsigned)meta[8];
-  const float vwf = g_sw[(2 * t + 0) * 64 + lane0];  // falling-edge weight of bin klo+lane
-  const float vwr = g_sw[(2 * t + 1) * 64 + lane0];  // rising-edge weight
+  const int klo = meta[0], nchunks = meta[1], m0 = meta[2], npre = meta[3];
+  // this wave's sweep program: one 32-dword record per 8-bin chunk
+  const float4* __restrict__ prog =
+      reinterpret_cast<const float4*>(g_sw) + t * (MEL_MAXC * MEL_REC / 4);
 
   // ---- span prefetch: the tile's samples -> registers -------------------------------
   int tid = tid0, lane = lane0;
@@ -247,6 +251,7 @@ __global__ __launch_bounds__(w400::WG, 4) void logmel400_kernel(
     STAMP(12)
 
     float* __restrict__ P = lds;  // bin-major: P[k][frame]
+    P[FT * (M + 1) + tid] = 0.0f;  // rows 201..208: read (with zero weights) by a padded last chunk
     {
       float* __restrict__ pa = P + FT * a0k + lane;         // bins a0k + 25*k2
       float* __restrict__ pb = P + FT * (25 - a0k) + lane;  // bins (25-a0k) + 25*k2
@@ -277,57 +282,66 @@ __global__ __launch_bounds__(w400::WG, 4) void logmel400_kernel(
 
     // ---- mel sweep + log epilogue ---------------------------------------------------------
     if (!(p.dbg & 1)) {
-      const long long f = f0 + lane;
-      const bool valid = (f < p.F) && !(p.dbg & 4);
-      float* __restrict__ optr = g_out + ((b * p.n_mels + m0) * p.F + f);
+      const bool valid = f0 + lane < p.F;
+      // wave-uniform row pointer + lane offset: the row step is scalar arithmetic
+      float* __restrict__ rowp = g_out + ((b * p.n_mels + m0) * p.F + f0);
       const float* __restrict__ pr = P + FT * klo + lane;
-      float prevR = 0.0f;
+      float acc_cur = 0.0f, acc_next = 0.0f;
       float vmax = -INFINITY, vmin = INFINITY;
-      int bin = 0;  // bins consumed so far (uniform)
-      for (int sg = 0; sg < nseg; ++sg) {
-        const unsigned cw = sg < 8 ? cw0 : (sg < 16 ? cw1 : (sg < 24 ? cw2 : (sg < 32 ? cw3 : cw4)));
-        const int n = (cw >> (4 * (sg & 7))) & 15;
-        float accR = 0.0f, accF = 0.0f;
-        const float* __restrict__ q = pr + FT * bin;
-        // straight-line per bin count, so all LDS reads of a segment are in flight together
-        switch (n) {
-#define MIA_CASE(NB)                                              \
-  case NB: {                                                      \
-    float pv[NB];                                                 \
-    _Pragma("unroll") for (int j = 0; j < NB; ++j) pv[j] = q[FT * j]; \
-    _Pragma("unroll") for (int j = 0; j < NB; ++j) {              \
-      accF = fmaf(readlane_f(vwf, bin + j), pv[j], accF);         \
-      accR = fmaf(readlane_f(vwr, bin + j), pv[j], accR);         \
-    }                                                             \
-  } break;
-          MIA_CASE(1) MIA_CASE(2) MIA_CASE(3) MIA_CASE(4) MIA_CASE(5) MIA_CASE(6) MIA_CASE(7)
-          MIA_CASE(8) MIA_CASE(9) MIA_CASE(10) MIA_CASE(11) MIA_CASE(12) MIA_CASE(13)
-          MIA_CASE(14) MIA_CASE(15)
-#undef MIA_CASE
-          default: break;
+      auto emit = [&]() {  // the filter in progress is complete
+        float outv = acc_cur;
+        if (EPI == MIA_EPI_WHISPER) {
+          // (log10(max(x, 1e-10)) + 4) / 4 as one FMA on log2
+          outv = fmaf(__builtin_amdgcn_logf(fmaxf(acc_cur, 1e-10f)), 0.25f * 0.30102999566f, 1.0f);
+        } else if (EPI == MIA_EPI_DB) {
+          // coef * log10(max(x, amin) / ref)
+          outv = fmaf(__builtin_amdgcn_logf(fmaxf(acc_cur, p.amin)), p.coef * 0.30102999566f,
+                      p.db_floor_shift);
         }
-        bin += n;
-        if (sg > 0) {  // filter m0 + sg - 1 is complete: rising part + falling part
-          const float acc = prevR + accF;
-          float outv = acc;
-          if (EPI == MIA_EPI_WHISPER) {
-            const float yv = acc <= 1e-10f ? -10.0f : __log10f(acc);
-            vmax = fmaxf(vmax, yv);
-            outv = (yv + 4.0f) * 0.25f;
-            vmin = fminf(vmin, outv);
-          } else if (EPI == MIA_EPI_DB) {
-            outv = acc <= p.amin ? p.db_floor : p.coef * __log10f(acc * p.inv_ref);
-            vmax = fmaxf(vmax, outv);
-            vmin = fminf(vmin, outv);
+        if (EPI != MIA_EPI_NONE) {
+          vmax = fmaxf(vmax, outv);
+          vmin = fminf(vmin, outv);
+        }
+        if (valid) rowp[lane] = outv;
+        rowp += p.F;
+        acc_cur = acc_next;
+        acc_next = 0.0f;
+      };
+      for (int e = 0; e < npre; ++e) emit();
+      if (nchunks > 0) {
+        float4 wa0 = prog[0], wa1 = prog[1], wb0 = prog[2], wb1 = prog[3];
+        unsigned ctrl = __builtin_bit_cast(unsigned, prog[4].x);
+        float pv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pv[j] = pr[FT * j];
+        for (int c = 0; c < nchunks; ++c) {
+          const float4 ca0 = wa0, ca1 = wa1, cb0 = wb0, cb1 = wb1;
+          const unsigned cc = ctrl;
+          float cv[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) cv[j] = pv[j];
+          {  // next chunk's record and power values, in flight during this chunk's FMAs
+            const int cn = c + 1 < nchunks ? c + 1 : c;
+            const float4* __restrict__ rn = prog + cn * (MEL_REC / 4);
+            wa0 = rn[0]; wa1 = rn[1]; wb0 = rn[2]; wb1 = rn[3];
+            ctrl = __builtin_bit_cast(unsigned, rn[4].x);
+            const float* __restrict__ qn = pr + FT * 8 * cn;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pv[j] = qn[FT * j];
           }
-          if (valid) *optr = outv;
-          optr += p.F;
+          const float wa[8] = {ca0.x, ca0.y, ca0.z, ca0.w, ca1.x, ca1.y, ca1.z, ca1.w};
+          const float wb[8] = {cb0.x, cb0.y, cb0.z, cb0.w, cb1.x, cb1.y, cb1.z, cb1.w};
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            acc_cur = fmaf(wa[j], cv[j], acc_cur);
+            acc_next = fmaf(wb[j], cv[j], acc_next);
+            for (unsigned n = (cc >> (4 * j)) & 15u; n > 0; --n) emit();
+          }
         }
-        prevR = accR;
       }
 
       if (EPI != MIA_EPI_NONE && g_maxkey != nullptr) {
-        if (!(f < p.F)) {
+        if (!valid) {
           vmax = -INFINITY;
           vmin = INFINITY;
         }
@@ -337,6 +351,8 @@ __global__ __launch_bounds__(w400::WG, 4) void logmel400_kernel(
           vmin = fminf(vmin, __shfl_xor(vmin, off));
         }
         if (lane == 0) {
+          // the max key is kept on the log10 scale (before the (.+4)/4 map)
+          if (EPI == MIA_EPI_WHISPER) vmax = fmaf(vmax, 4.0f, -4.0f);
           atomicMax(g_maxkey + b, float_to_key(vmax));
           atomicMin(g_minkey + b, float_to_key(vmin));
         }

@@ -81,8 +81,8 @@ struct mia_plan {
   // extra tables of the n_fft = 400 / hop = 160 kernel (null when not applicable)
   float2* d_tw2 = nullptr;       // [25][8]  exp(-2 pi i t k1 / 200)
   float2* d_tws = nullptr;       // [13][8]  exp(-2 pi i (k1 + 25 k2) / 400)
-  int* d_sweep_meta = nullptr;   // [8][16] per-wave sweep program (see logmel400.hip)
-  float* d_sweep_w = nullptr;    // [8][2][64] falling / rising weight of the wave's i-th bin
+  int* d_sweep_meta = nullptr;   // [8][16] per-wave sweep header: first bin, chunks, first filter
+  float* d_sweep_w = nullptr;    // [8][13][32] per-wave sweep program (see logmel400.hip)
 };
 
 namespace mia {
@@ -107,6 +107,7 @@ struct FwdParams {
   int epi;         // 0: none, 1: whisper log10 -> (y+4)/4, 2: dB
   float amin, inv_ref, coef;
   float db_floor;      // coef*log10(amin/max(ref,amin)), the value of clamped inputs
+  float db_floor_shift;  // coef*log10(1/max(ref,amin)): additive form of the division by ref
   int* clip_max_key;   // B (+1) keys of the per-clip maximum, or nullptr
   int* clip_min_key;   // B keys of the per-clip minimum of the stored values
   int dbg;

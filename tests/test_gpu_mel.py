@@ -81,7 +81,7 @@ def test_logmel_whisper_clamped_inputs(gpu):
 
     clips = np.stack([
         _speechlike(160000, 1),
-        np.zeros(160000, np.float32),                                # silence -> exactly -1.5
+        np.zeros(160000, np.float32),                                # silence -> -1.5
         _noise(160000, 3) * 1e-6,                                    # 1e-6-scaled
         np.concatenate([np.zeros(80000, np.float32), _noise(80000, 4)]),
     ])
@@ -90,7 +90,8 @@ def test_logmel_whisper_clamped_inputs(gpu):
     for b in range(len(clips)):
         ref = o.compute_log_mel_spectrogram(clips[b], n_mels=128)
         assert np.abs(got[b] - ref).max() <= 1e-4, b
-    assert np.all(got[1] == -1.5)
+    # log10(float32(1e-10)) is -10 only to within an ulp (NumPy gives -1.5000002 here)
+    assert np.abs(got[1] + 1.5).max() <= 1e-6
     got_g = compute_log_mel_spectrogram(torch.from_numpy(clips).to(gpu), n_mels=128)
     ref_g = o.compute_log_mel_spectrogram(clips, n_mels=128)
     assert np.abs(got_g.cpu().numpy() - ref_g).max() <= 1e-4
