@@ -185,8 +185,8 @@ static void plan_free(mia_plan* p) {
   (void)hipFree(p->d_row_off);
   (void)hipFree(p->d_wts);
   (void)hipFree(p->d_dct);
-  (void)hipFree(p->d_tw2);
-  (void)hipFree(p->d_tws);
+  (void)hipFree(p->d_win16);
+  (void)hipFree(p->d_tw16);
   (void)hipFree(p->d_sweep_meta);
   (void)hipFree(p->d_sweep_w);
   delete p;
@@ -206,7 +206,8 @@ static int upload(Tp** dst, const std::vector<Tp>& src) {
 // Tables of the lane-per-frame n_fft=400 / hop=160 kernel (logmel400.hip).
 // Returns MIA_OK and leaves the plan without them when the filterbank is not
 // of the "two taps per bin" triangular form the sweep needs.
-static int build_w400_tables(mia_plan* p, const float* basis, int n_mels, int bins) {
+static int build_w400_tables(mia_plan* p, const float* window, const float* basis, int n_mels,
+                             int bins) {
   // segment s(k) of every bin: the bin feeds the rising edge of filter s and
   // the falling edge of filter s-1
   std::vector<int> seg((size_t)bins);
@@ -259,10 +260,10 @@ static int build_w400_tables(mia_plan* p, const float* basis, int n_mels, int bi
     klo = lo < 0 ? 0 : lo;
     return n;
   };
-  // Deal contiguous runs of filters to the 8 waves with even sweep cost
+  // Deal contiguous runs of filters to the waves with even sweep cost
   // (about 2 instructions per bin, 7 per filter, 10 per 8-bin chunk): the
   // smallest bound for which a greedy left-to-right deal places every filter.
-  constexpr int kMaxChunks = 13, kChunk = 8, kRec = 32;
+  constexpr int kWaves = W400_WAVES, kMaxChunks = W400_MEL_MAXC, kChunk = 8, kRec = W400_MEL_REC;
   auto cost = [&](int m0, int m1) {  // filters [m0, m1)
     int klo = 0;
     const int nb = bins_of(m0, m1, klo);
@@ -270,7 +271,7 @@ static int build_w400_tables(mia_plan* p, const float* basis, int n_mels, int bi
   };
   auto deal = [&](double bound, int* starts) {
     int m = 0;
-    for (int w = 0; w < 8; ++w) {
+    for (int w = 0; w < kWaves; ++w) {
       starts[w] = m;
       while (m < n_mels) {
         int klo = 0;
@@ -280,10 +281,10 @@ static int build_w400_tables(mia_plan* p, const float* basis, int n_mels, int bi
         ++m;
       }
     }
-    starts[8] = m;
+    starts[kWaves] = m;
     return m == n_mels;
   };
-  int starts[9];
+  int starts[kWaves + 1];
   double lo_b = 0.0, hi_b = 1e9;
   if (!deal(hi_b, starts)) return MIA_OK;  // does not fit the per-wave limits
   for (int iter = 0; iter < 60; ++iter) {
@@ -298,9 +299,9 @@ static int build_w400_tables(mia_plan* p, const float* basis, int n_mels, int bi
   //   segment m0     : rising edge of m0          -> wA (the filter in progress)
   //   segment m0+j   : falling edge of m0+j-1     -> wA, rising edge of m0+j -> wB
   //   segment m1     : falling edge of m1-1       -> wA, nothing            -> wB
-  std::vector<int> meta(8 * 16, 0);
-  std::vector<float> sw((size_t)8 * kMaxChunks * kRec, 0.0f);
-  for (int w = 0; w < 8; ++w) {
+  std::vector<int> meta(kWaves * 16, 0);
+  std::vector<float> sw((size_t)kWaves * kMaxChunks * kRec, 0.0f);
+  for (int w = 0; w < kWaves; ++w) {
     const int m0 = starts[w];
     const int m1 = starts[w + 1];
     int* mt = &meta[(size_t)w * 16];
@@ -341,22 +342,19 @@ static int build_w400_tables(mia_plan* p, const float* basis, int n_mels, int bi
     mt[3] = npre;
     if (i != nb) return MIA_OK;
   }
-  std::vector<float2> tw2(25 * 8), tws(13 * 8);
-  for (int k1 = 0; k1 < 25; ++k1) {
-    for (int t = 0; t < 8; ++t) {
-      const double a = -2.0 * M_PI * double((t * k1) % 200) / 200.0;
-      tw2[(size_t)k1 * 8 + t] = {(float)std::cos(a), (float)std::sin(a)};
-    }
-  }
-  for (int k1 = 0; k1 < 13; ++k1) {
-    for (int k2 = 0; k2 < 8; ++k2) {
-      const double a = -2.0 * M_PI * double(k1 + 25 * k2) / 400.0;
-      tws[(size_t)k1 * 8 + k2] = {(float)std::cos(a), (float)std::sin(a)};
+  // FFT tables: role t's window taps and its step twiddles
+  std::vector<float> win16((size_t)kWaves * 32, 0.0f);
+  std::vector<float2> tw16((size_t)kWaves * 16, float2{1.0f, 0.0f});
+  for (int t = 0; t < kWaves; ++t) {
+    for (int r = 0; r < 25; ++r) win16[(size_t)t * 32 + r] = window[t + 16 * r];
+    for (int k1 = 0; k1 < 13; ++k1) {
+      const double a = -2.0 * M_PI * double((t * k1) % 400) / 400.0;
+      tw16[(size_t)t * 16 + k1] = {(float)std::cos(a), (float)std::sin(a)};
     }
   }
   int rc;
-  if ((rc = upload(&p->d_tw2, tw2)) != MIA_OK) return rc;
-  if ((rc = upload(&p->d_tws, tws)) != MIA_OK) return rc;
+  if ((rc = upload(&p->d_win16, win16)) != MIA_OK) return rc;
+  if ((rc = upload(&p->d_tw16, tw16)) != MIA_OK) return rc;
   if ((rc = upload(&p->d_sweep_meta, meta)) != MIA_OK) return rc;
   if ((rc = upload(&p->d_sweep_w, sw)) != MIA_OK) return rc;
   return MIA_OK;
@@ -433,7 +431,7 @@ int mia_plan_create(const mia_plan_desc* d, mia_plan** out) {
     if ((rc = upload(&p->d_row_off, off)) != MIA_OK) return fail(rc);
     if ((rc = upload(&p->d_wts, wts)) != MIA_OK) return fail(rc);
     if (N == 400 && d->hop_length == 160 && d->power == 2.0f) {
-      rc = build_w400_tables(p, d->mel_basis, d->n_mels, bins);
+      rc = build_w400_tables(p, d->window, d->mel_basis, d->n_mels, bins);
       if (rc != MIA_OK) return fail(rc);
     }
   }
@@ -580,7 +578,7 @@ extern "C" size_t mia_mel_workspace_bytes(const mia_plan* plan, int64_t B, int64
 // The lane-per-frame kernel when the plan has its tables, else the generic one.
 static int forward_mel_dispatch(const mia_plan* plan, const FwdParams& p, hipStream_t s) {
   if (plan->d_sweep_meta != nullptr) {
-    W400Tables tb{plan->d_tw2, plan->d_tws, plan->d_sweep_meta, plan->d_sweep_w};
+    W400Tables tb{plan->d_win16, plan->d_tw16, plan->d_sweep_meta, plan->d_sweep_w};
     return launch_logmel400(p, tb, s);
   }
   return launch_forward(plan, p, 1, s);

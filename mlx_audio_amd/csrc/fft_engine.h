@@ -229,4 +229,51 @@ template <> struct Dft<20> : DftCT<4, 5> {};
 template <> struct Dft<25> : DftCT<5, 5> {};
 template <> struct Dft<32> : DftCT<4, 8> {};
 
+// ----------------------------------------------------------------------------
+// Real-input DFTs.  rdft5: 5 real samples -> X[0] (real), X[1], X[2]
+// (X[3] = conj X[2], X[4] = conj X[1]).
+// ----------------------------------------------------------------------------
+__device__ __forceinline__ void rdft5(float a0, float a1, float a2, float a3, float a4, float& X0,
+                                      float2& X1, float2& X2) {
+  constexpr float c1 = 0.30901699437494742410f;   // cos(2pi/5)
+  constexpr float c2 = -0.80901699437494742410f;  // cos(4pi/5)
+  constexpr float s1 = 0.95105651629515357212f;   // sin(2pi/5)
+  constexpr float s2 = 0.58778525229247312917f;   // sin(4pi/5)
+  const float p = a1 + a4, q = a2 + a3, u = a1 - a4, v = a2 - a3;
+  X0 = a0 + p + q;
+  X1 = {a0 + c1 * p + c2 * q, -(s1 * u + s2 * v)};
+  X2 = {a0 + c2 * p + c1 * q, s1 * v - s2 * u};
+}
+
+// rdft25: 25 real samples -> bins 0..12 (bin 0 has zero imaginary part).
+// n = 5 n1 + n2, k = k1 + 5 k2; only k1 = 0, 1, 2 are computed, the columns
+// k1 = 3, 4 being their conjugates: X[9] = conj X[16], X[4] = conj X[21],
+// X[8] = conj X[17], X[3] = conj X[22].
+__device__ __forceinline__ void rdft25(const float (&x)[25], float2 (&X)[13]) {
+  float A0[5];
+  float2 B1[5], B2[5];
+  static_for<0, 5>([&](auto n2c) {
+    constexpr int n2 = decltype(n2c)::value;
+    float2 a1, a2;
+    rdft5(x[n2], x[5 + n2], x[10 + n2], x[15 + n2], x[20 + n2], A0[n2], a1, a2);
+    B1[n2] = mul_w<n2, 25>(a1);
+    B2[n2] = mul_w<2 * n2, 25>(a2);
+  });
+  float r0;
+  rdft5(A0[0], A0[1], A0[2], A0[3], A0[4], r0, X[5], X[10]);
+  X[0] = {r0, 0.0f};
+  Dft<5>::run(B1);
+  X[1] = B1[0];
+  X[6] = B1[1];
+  X[11] = B1[2];
+  X[9] = cconj(B1[3]);
+  X[4] = cconj(B1[4]);
+  Dft<5>::run(B2);
+  X[2] = B2[0];
+  X[7] = B2[1];
+  X[12] = B2[2];
+  X[8] = cconj(B2[3]);
+  X[3] = cconj(B2[4]);
+}
+
 }  // namespace mia

@@ -1,100 +1,145 @@
 // Fused mel front-end for n_fft = 400, hop = 160 (Whisper's framing):
 // pad + frame + window + 400-point real FFT + |X|^2 + mel band projection +
-// log epilogue in one persistent kernel; a 512-thread workgroup walks a run of
+// log epilogue in one persistent kernel; a 1024-thread workgroup walks a run of
 // 64-frame tiles.
 //
-// Mapping.  LANE = frame, WAVE = role inside the FFT.  The 200-point complex
-// transform of z[n] = x[2n] + i x[2n+1] is split 8 x 25:
-//   pass 1: wave t (0..7) does, for its lane's frame, the radix-25 DFT of
-//           z[t + 8r], r = 0..24;
-//   pass 2: the 25 radix-8 butterflies over t are dealt to the waves in pairs
-//           (k1, 25-k1), whose outputs are the bin pairs (k, 200-k) of the
-//           real-FFT split step, so split and |X|^2 run in registers.
-// Because the role is wave-uniform every twiddle, window tap and LDS offset
-// is a scalar or an instruction immediate, all 64 lanes work, and with odd /
-// 2-mod-4 row strides every LDS access is bank-conflict free.
+// Mapping.  LANE = frame, WAVE = role inside the FFT.  The real transform is
+// split 16 x 25 on the real samples themselves:
+//   pass 1: wave t (0..15) does, for its lane's frame, the REAL-input radix-25
+//           DFT of x[t + 16 r], r = 0..24 (bins 0..12; the rest are conjugates),
+//           and applies the step twiddle exp(-2 pi i t k1 / 400);
+//   pass 2: wave k1 (0..12) does the radix-16 butterfly over t, which yields
+//           X[k1 + 25 k2], k2 = 0..15.  Bins above 200 are the conjugates of
+//           bins 400 - k, so the 13 butterflies give every |X[k]|^2, k = 0..200,
+//           with no split step.
+// Because the role is wave-uniform every twiddle, window tap and LDS offset is
+// a scalar or an instruction immediate and all 64 lanes work.  Sixteen light
+// waves (<= 64 VGPRs) instead of eight heavy ones put 8 waves on every SIMD.
 //
 // Mel stage.  Each bin k of a triangular filterbank feeds at most two
 // filters: the rising edge of filter s(k) and the falling edge of filter
-// s(k)-1.  Every wave owns a run of filters and sweeps the bins of those
-// filters once: two FMAs per bin, one emit (log, store, running max/min) per
-// filter.  The per-bin weights live in two VGPRs (lane i = i-th bin of the
-// wave) and are broadcast with v_readlane; the control (when a filter is
-// complete) is a 2-bit-per-bin scalar mask.
+// s(k)-1.  Every wave owns a run of filters and sweeps their bins once in
+// chunks of 8: the chunk's weights and control word arrive by scalar loads
+// (two FMAs per bin with an SGPR operand), and a filter is emitted (log,
+// store, running max/min) when the control word says it is complete.
 //
-// LDS (one 53.8 KB buffer, reused three times per tile, 2 workgroups per CU):
-//   span : the tile's 10480 samples, rows of 160 samples at stride 162 dwords
-//   ex   : pass-1 -> pass-2 exchange, per frame 8 roles x 13 complex, stride 210
-//   P    : power spectrum, bin-major [201][64]
-// The next tile's samples are prefetched into registers while the current
-// tile computes.
+// LDS (one 57.9 KB buffer, reused three times per tile, 2 workgroups per CU):
+//   span : the tile's 10480 samples, rows of 160 samples at stride 161 dwords
+//   ex   : pass-1 -> pass-2 exchange in two phases (k1 = 0..6, then 7..12),
+//          per frame 16 roles x 7 complex, stride 226 dwords
+//   P    : power spectrum, bin-major [201 (+8 zero rows)][64]
 #include "fft_engine.h"
 #include "mia_internal.h"
 
 namespace mia {
 
 namespace w400 {
-constexpr int N = 400, M = 200, HOP = 160, FT = 64, WG = 512;
-constexpr int SPAN = (FT - 1) * HOP + N;  // 10480 samples per tile
-constexpr int SPAN4 = SPAN / 4;           // 2620 float4
-constexpr int NPRE = (SPAN4 + WG - 1) / WG;  // 6 float4 per thread
-constexpr int RS = 162;                   // span row stride (dwords)
-constexpr int ES = 210;                   // exchange stride per frame (dwords)
-constexpr int LDS_DWORDS = FT * ES;       // 13440 >= 66*162 and >= 201*64 (+8 rows slack)
-constexpr int MEL_MAXC = 13;              // mel sweep: chunks of 8 bins per wave, at most
-constexpr int MEL_REC = 32;               // dwords per chunk record: wA[8], wB[8], ctrl, pad
+constexpr int N = 400, HOP = 160, FT = 64, NW = W400_WAVES, WG = NW * 64;
+constexpr int BINS = N / 2 + 1;              // 201
+constexpr int SPAN = (FT - 1) * HOP + N;     // 10480 samples per tile
+constexpr int SPAN4 = SPAN / 4;              // 2620 float4
+constexpr int NPRE = (SPAN4 + WG - 1) / WG;  // 3 float4 per thread
+constexpr int RS = 161;                      // span row stride (dwords), odd: conflict-free b32
+constexpr int ES = 226;                      // exchange stride per frame (dwords), 2 mod 4
+constexpr int LDS_DWORDS = FT * ES;          // 14464
+static_assert(NW == 16, "the FFT split is 16 x 25");
 static_assert(LDS_DWORDS >= ((SPAN + HOP - 1) / HOP) * RS, "span fits");
-static_assert(LDS_DWORDS >= (M + 1 + 8) * FT, "power tile (+ read slack) fits");
+static_assert(LDS_DWORDS >= (BINS + 8) * FT, "power tile (+ zero rows) fits");
 }  // namespace w400
-
-// Butterflies of pass 2 owned by each wave: a0 (+ partner 25-a0), optional a1
-// (+ partner 25-a1, or no partner when a1 == 0).
-__constant__ int kW400A0[8] = {1, 3, 5, 7, 9, 10, 11, 12};
-__constant__ int kW400A1[8] = {2, 4, 6, 8, 0, -1, -1, -1};
-
-// One split + power step for the bin pair (k, 200-k): U = Z[k], V = Z[200-k].
-__device__ __forceinline__ void split_power(float2 U, float2 V, float2 w, float& pk,
-                                            float& pmk) {
-  const float2 E = {U.x + V.x, U.y - V.y};
-  const float2 O = {U.y + V.y, V.x - U.x};
-  const float2 WO = cmul(O, w);
-  const float ax = E.x + WO.x, ay = E.y + WO.y;
-  const float bx = E.x - WO.x, by = E.y - WO.y;
-  pk = 0.25f * (ax * ax + ay * ay);
-  pmk = 0.25f * (bx * bx + by * by);
-}
-
-__device__ __forceinline__ float readlane_f(float v, int l) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
-}
 
 __device__ unsigned long long* g_dbgbuf = nullptr;
 #ifdef MIA_W400_STAMPS
 #define STAMP(i)                                                                          \
   if ((p.dbg & 8) && g_dbgbuf && blockIdx.x == 77 && (threadIdx.x & 63) == 0 && it < 4)    \
-    g_dbgbuf[(it * 8 + (threadIdx.x >> 6)) * 16 + (i)] = __builtin_readcyclecounter();
+    g_dbgbuf[(it * 16 + (threadIdx.x >> 6)) * 16 + (i)] = __builtin_readcyclecounter();
 #else
 #define STAMP(i)
 #endif
 
+// A tile whose samples all lie inside the clip (no padding) and start on a
+// 16-byte boundary can be fetched as float4.
+__device__ __forceinline__ bool tile_interior(const float* yb, long long s_begin, long long T) {
+  return s_begin >= 0 && s_begin + w400::SPAN <= T &&
+         ((reinterpret_cast<uintptr_t>(yb + s_begin) & 15) == 0);
+}
+
+// Mel sweep of one wave over the power tile.  FULL: every lane's frame exists.
+template <int EPI, bool FULL>
+__device__ __forceinline__ void mel_sweep(const FwdParams& p, const float* __restrict__ P,
+                                          const float4* __restrict__ prog, int klo, int nchunks,
+                                          int npre, float* __restrict__ rowp, int lane, bool valid,
+                                          float& vmax, float& vmin) {
+  using namespace w400;
+  const float* __restrict__ pr = P + FT * klo + lane;
+  float acc_cur = 0.0f, acc_next = 0.0f;
+  auto emit = [&]() {  // the filter in progress is complete
+    float outv = acc_cur;
+    if (EPI == MIA_EPI_WHISPER) {
+      // (log10(max(x, 1e-10)) + 4) / 4 as one FMA on log2
+      outv = fmaf(__builtin_amdgcn_logf(fmaxf(acc_cur, 1e-10f)), 0.25f * 0.30102999566f, 1.0f);
+    } else if (EPI == MIA_EPI_DB) {
+      // coef * log10(max(x, amin) / ref)
+      outv = fmaf(__builtin_amdgcn_logf(fmaxf(acc_cur, p.amin)), p.coef * 0.30102999566f,
+                  p.db_floor_shift);
+    }
+    if (EPI != MIA_EPI_NONE) {
+      vmax = fmaxf(vmax, outv);
+      vmin = fminf(vmin, outv);
+    }
+    if ((FULL || valid) && !(p.dbg & 4)) rowp[lane] = outv;
+    rowp += p.F;
+    acc_cur = acc_next;
+    acc_next = 0.0f;
+  };
+  for (int e = 0; e < npre; ++e) emit();
+  if (nchunks <= 0) return;
+  float4 wa0 = prog[0], wa1 = prog[1], wb0 = prog[2], wb1 = prog[3];
+  unsigned ctrl = __builtin_bit_cast(unsigned, prog[4].x);
+  float pv[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) pv[j] = pr[FT * j];
+  for (int c = 0; c < nchunks; ++c) {
+    const float4 ca0 = wa0, ca1 = wa1, cb0 = wb0, cb1 = wb1;
+    const unsigned cc = ctrl;
+    float cv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) cv[j] = pv[j];
+    {  // next chunk's record and power values, in flight during this chunk's FMAs
+      const int cn = c + 1 < nchunks ? c + 1 : c;
+      const float4* __restrict__ rn = prog + cn * (W400_MEL_REC / 4);
+      wa0 = rn[0];
+      wa1 = rn[1];
+      wb0 = rn[2];
+      wb1 = rn[3];
+      ctrl = __builtin_bit_cast(unsigned, rn[4].x);
+      const float* __restrict__ qn = pr + FT * 8 * cn;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pv[j] = qn[FT * j];
+    }
+    const float wa[8] = {ca0.x, ca0.y, ca0.z, ca0.w, ca1.x, ca1.y, ca1.z, ca1.w};
+    const float wb[8] = {cb0.x, cb0.y, cb0.z, cb0.w, cb1.x, cb1.y, cb1.z, cb1.w};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      acc_cur = fmaf(wa[j], cv[j], acc_cur);
+      acc_next = fmaf(wb[j], cv[j], acc_next);
+      for (unsigned n = (cc >> (4 * j)) & 15u; n > 0; --n) emit();
+    }
+  }
+}
+
 template <int EPI>
-__global__ __launch_bounds__(w400::WG, 4) void logmel400_kernel(
+__global__ __launch_bounds__(w400::WG, 8) void logmel400_kernel(
     FwdParams p, const float* __restrict__ g_y, const float* __restrict__ g_win,
-    const float2* __restrict__ g_tw2, const float2* __restrict__ g_tws,
-    const int* __restrict__ g_meta, const float* __restrict__ g_sw, float* __restrict__ g_out,
-    int* __restrict__ g_maxkey, int* __restrict__ g_minkey) {
+    const float2* __restrict__ g_tw, const int* __restrict__ g_meta,
+    const float* __restrict__ g_sw, float* __restrict__ g_out, int* __restrict__ g_maxkey,
+    int* __restrict__ g_minkey) {
   // Every table and the input come in as __restrict__ kernel arguments so that
   // their wave-uniform loads are scalar (s_load) loads; through a struct member
   // the compiler must assume they alias the output and falls back to vector loads.
   using namespace w400;
-#ifdef MIA_W400_LDS_PAD
-  __shared__ __attribute__((aligned(16))) float lds[LDS_DWORDS + MIA_W400_LDS_PAD];
-#else
   __shared__ __attribute__((aligned(16))) float lds[LDS_DWORDS];
-#endif
 
   const int tid0 = threadIdx.x;
-  const int lane0 = tid0 & 63;
   const int t = __builtin_amdgcn_readfirstlane(tid0 >> 6);  // role
   const int total = (int)(p.B * p.tiles);  // launcher guarantees < 2^31
   const int first = (int)blockIdx.x * p.tiles_per_wg;
@@ -102,18 +147,22 @@ __global__ __launch_bounds__(w400::WG, 4) void logmel400_kernel(
   if (first >= last) return;
 
   // ---- per-wave constants -------------------------------------------------------
-  const int a0k = kW400A0[t];
-  const int a1k = kW400A1[t];
   const int* __restrict__ meta = g_meta + 16 * t;
   const int klo = meta[0], nchunks = meta[1], m0 = meta[2], npre = meta[3];
   // this wave's sweep program: one 32-dword record per 8-bin chunk
   const float4* __restrict__ prog =
-      reinterpret_cast<const float4*>(g_sw) + t * (MEL_MAXC * MEL_REC / 4);
+      reinterpret_cast<const float4*>(g_sw) + t * (W400_MEL_MAXC * W400_MEL_REC / 4);
+  const bool bfly = t < 13;             // this wave owns pass-2 butterfly k1 = t
+  const int bslot = t < 7 ? t : t - 7;  // its slot inside its exchange phase
 
-  // ---- span prefetch: the tile's samples -> registers -------------------------------
-  int tid = tid0, lane = lane0;
+  int tid = tid0, lane = tid0 & 63;
   int cur_b = first / p.tiles;             // clip and tile-in-clip of the current tile,
   int cur_tile = first - cur_b * p.tiles;  // advanced incrementally
+
+  if (((p.dbg & 16) && blockIdx.x >= gridDim.x / 2) || ((p.dbg & 32) && (blockIdx.x & 1))) {
+    __builtin_amdgcn_s_sleep(127);
+    if (p.dbg & 64) __builtin_amdgcn_s_sleep(127);
+  }
 
   int it = 0;
   for (int idx = first; idx < last; ++idx, ++it) {
@@ -124,41 +173,38 @@ __global__ __launch_bounds__(w400::WG, 4) void logmel400_kernel(
       ++cur_b;
     }
     const long long f0 = (long long)tile * FT;
-    // Re-derive the lane-dependent addresses every tile instead of keeping a
-    // few dozen loop-invariant VGPRs alive across the whole loop body.
+    // Re-derive the lane-dependent addresses every tile instead of keeping
+    // loop-invariant VGPRs alive across the whole loop body.
     tid = tid0;
     asm volatile("" : "+v"(tid)::"memory");  // also keeps this tile's loads below this point
     lane = tid & 63;
     STAMP(0)
 
-    // ---- stage the tile's samples: global -> LDS, rows of 160 at stride 162 ---------
+    // ---- stage the tile's samples: global -> LDS, rows of 160 at stride 161 ---------
     {
       const float* __restrict__ yb = g_y + b * p.T;
       const long long s_begin = f0 * HOP - p.pad;
-      // tiles wholly inside the clip (no padding, 16-byte aligned) take the
-      // vector path; the edge tiles of a clip a plain per-sample loop
-      const bool interior = s_begin >= 0 && s_begin + SPAN <= p.T &&
-                            ((reinterpret_cast<uintptr_t>(yb + s_begin) & 15) == 0);
-      if (p.dbg & 2) {
-        for (int s = tid; s < LDS_DWORDS; s += WG) lds[s] = 0.001f * (s & 63);
-      } else if (interior) {
+      if (tile_interior(yb, s_begin, p.T)) {
         const float4* __restrict__ src = reinterpret_cast<const float4*>(yb + s_begin);
-        float4 pre[NPRE];
+        float4 now[NPRE];
 #pragma unroll
         for (int i = 0; i < NPRE; ++i) {
           const int q = tid + i * WG;
-          pre[i] = src[q < SPAN4 ? q : SPAN4 - 1];
+          now[i] = src[q < SPAN4 ? q : SPAN4 - 1];
         }
 #pragma unroll
         for (int i = 0; i < NPRE; ++i) {
           const int q = tid + i * WG;
           if (q < SPAN4) {
-            float2* dst = reinterpret_cast<float2*>(lds + RS * (q / 40) + 4 * (q % 40));
-            dst[0] = {pre[i].x, pre[i].y};
-            dst[1] = {pre[i].z, pre[i].w};
+            float* dst = lds + RS * (q / 40) + 4 * (q % 40);
+            dst[0] = now[i].x;
+            dst[1] = now[i].y;
+            dst[2] = now[i].z;
+            dst[3] = now[i].w;
           }
         }
       } else {
+        // edge tiles of a clip (padding, or a clip start that is not 16-byte aligned)
 #pragma unroll 1
         for (int s = tid; s < SPAN; s += WG) {
           lds[RS * (s / HOP) + (s % HOP)] = fetch_sample(yb, p.T, s_begin + s, p.pad_mode);
@@ -169,114 +215,82 @@ __global__ __launch_bounds__(w400::WG, 4) void logmel400_kernel(
     __syncthreads();
     STAMP(2)
 
-    // ---- pass 1: radix-25 over z[t + 8r] of this lane's frame --------------------------
-    float2 y[25];
+    float* __restrict__ P = lds;  // power tile, bin-major: P[k][frame]
+    if (!(p.dbg & 128)) {
+    // ---- pass 1: real radix-25 over x[t + 16 r] of this lane's frame, then the step
+    // twiddle exp(-2 pi i t k1 / 400) --------------------------------------------------
+    float2 y[13];
     {
-      const float2* __restrict__ sp = reinterpret_cast<const float2*>(lds + RS * lane + 2 * t);
-      const float2* __restrict__ win2 = reinterpret_cast<const float2*>(g_win) + t;
+      const float* __restrict__ sp = lds + RS * lane + t;
+      const float* __restrict__ wt = g_win + 32 * t;  // taps t + 16 r, r = 0..24
+      float x[25];
 #pragma unroll
-      for (int r = 0; r < 25; ++r) {
-        const float2 x = sp[(16 * r + 2 * (r / 10)) / 2];
-        const float2 w = win2[8 * r];
-        y[r] = {x.x * w.x, x.y * w.y};
-      }
-      Dft<25>::run(y);
+      for (int r = 0; r < 25; ++r) x[r] = sp[16 * r + r / 10] * wt[r];
+      rdft25(x, y);
+      const float2* __restrict__ tw = g_tw + 16 * t;
+#pragma unroll
+      for (int k = 1; k < 13; ++k) y[k] = cmul(y[k], tw[k]);
+      // All 13 outputs are final here: without this the scheduler sinks the second
+      // half of the transform below the exchange barriers, where its temporaries
+      // collide with the 16 pass-2 inputs.
+#pragma unroll
+      for (int k = 0; k < 13; ++k) asm volatile("" : "+v"(y[k].x), "+v"(y[k].y));
     }
     STAMP(3)
     __syncthreads();  // all span reads done; the buffer becomes the exchange area
     STAMP(4)
 
     float2* __restrict__ ex = reinterpret_cast<float2*>(lds);
-    const int exw = (ES * lane + 26 * t) / 2;  // this thread's 13 exchange slots
-    const int exr = (ES * lane) / 2;           // pass-2 reads: + 13*t' + c
+    const int exw = (ES * lane + 14 * t) / 2;  // this thread's 7 exchange slots
+    const int exr = (ES * lane) / 2 + bslot;   // pass-2 reads: + 7 * t'
+    float2 v[16];
 
-    // phase A: outputs k1 = 0..12
+    // phase A: outputs k1 = 0..6
 #pragma unroll
-    for (int c = 0; c < 13; ++c) ex[exw + c] = y[c];
+    for (int c = 0; c < 7; ++c) ex[exw + c] = y[c];
     STAMP(5)
     __syncthreads();
     STAMP(6)
-    float2 a0[8], a1[8];
+    // Every wave reads here (waves 7..15 overwrite the result after phase B), so
+    // that v is defined on all paths and never carried around the tile loop.
 #pragma unroll
-    for (int q = 0; q < 8; ++q) a0[q] = ex[exr + 13 * q + a0k];
-    if (a1k >= 0) {
-#pragma unroll
-      for (int q = 0; q < 8; ++q) a1[q] = ex[exr + 13 * q + a1k];
-    }
+    for (int q = 0; q < 16; ++q) v[q] = ex[exr + 7 * q];
     STAMP(7)
     __syncthreads();
     STAMP(8)
-    // phase B: outputs k1 = 13..24 at slot k1 - 13
+    // phase B: outputs k1 = 7..12 at slot k1 - 7
 #pragma unroll
-    for (int c = 0; c < 12; ++c) ex[exw + c] = y[13 + c];
+    for (int c = 0; c < 6; ++c) ex[exw + c] = y[7 + c];
     STAMP(9)
     __syncthreads();
     STAMP(10)
-    // ---- pass 2 + split + power ------------------------------------------------------
-    // The partner butterflies arrive with phase B: finish one pair at a time so
-    // that only one pair's inputs are live, keep the 16 + 16 power values in
-    // registers, and write them once every wave has read its exchange slots.
-    auto twiddle8 = [&](float2 (&v)[8], int k1) {
-      const float2* __restrict__ w = g_tw2 + 8 * k1;
+    if (t >= 7) {  // waves 13..15 read along (stale but finite slots) and discard the result
 #pragma unroll
-      for (int q = 1; q < 8; ++q) v[q] = cmul(v[q], w[q]);
-      Dft<8>::run(v);
-    };
-    auto do_pair = [&](float2 (&a)[8], int k1, float (&pk)[8], float (&pm)[8]) {
-      float2 bb[8];
-#pragma unroll
-      for (int q = 0; q < 8; ++q) bb[q] = ex[exr + 13 * q + (12 - k1)];
-      twiddle8(a, k1);
-      twiddle8(bb, 25 - k1);
-      const float2* __restrict__ ws = g_tws + 8 * k1;
-#pragma unroll
-      for (int k2 = 0; k2 < 8; ++k2) split_power(a[k2], bb[7 - k2], ws[k2], pk[k2], pm[7 - k2]);
-    };
-    float pk0[8], pm0[8], pk1[8], pm1[8];
-    do_pair(a0, a0k, pk0, pm0);
-    if (a1k > 0) {
-      do_pair(a1, a1k, pk1, pm1);
-    } else if (a1k == 0) {
-      // butterfly 0: bins 25*k2, paired inside the butterfly (k2 <-> 8-k2);
-      // pk1[k2] = bin 25*k2 (k2 = 0..4), pm1[k2] = bin 200 - 25*k2 (k2 = 0..3)
-      Dft<8>::run(a1);
-      const float2* __restrict__ ws = g_tws;
-      split_power(a1[0], a1[0], ws[0], pk1[0], pm1[0]);
-#pragma unroll
-      for (int k2 = 1; k2 < 4; ++k2) split_power(a1[k2], a1[8 - k2], ws[k2], pk1[k2], pm1[k2]);
-      pk1[4] = a1[4].x * a1[4].x + a1[4].y * a1[4].y;
+      for (int q = 0; q < 16; ++q) v[q] = ex[exr + 7 * q];
     }
+    // ---- pass 2: radix-16 over the roles; v[k2] = X[t + 25 k2] -----------------------
+    float pw[16];
+    Dft<16>::run(v);
+#pragma unroll
+    for (int k2 = 0; k2 < 16; ++k2) pw[k2] = fmaf(v[k2].x, v[k2].x, v[k2].y * v[k2].y);
     STAMP(11)
     __syncthreads();  // exchange reads done; the buffer becomes the power tile
     STAMP(12)
 
-    float* __restrict__ P = lds;  // bin-major: P[k][frame]
-    P[FT * (M + 1) + tid] = 0.0f;  // rows 201..208: read (with zero weights) by a padded last chunk
-    {
-      float* __restrict__ pa = P + FT * a0k + lane;         // bins a0k + 25*k2
-      float* __restrict__ pb = P + FT * (25 - a0k) + lane;  // bins (25-a0k) + 25*k2
+    if (tid < 512) P[FT * BINS + tid] = 0.0f;  // rows 201..208: read (zero weight) by a padded chunk
+    if (bfly) {
+      float* __restrict__ pa = P + FT * t + lane;          // bins t + 25 k2, k2 = 0..7
+      float* __restrict__ pb = P + FT * (200 - t) + lane;  // bins 400 - (t + 25 k2), k2 = 8..15
 #pragma unroll
-      for (int k2 = 0; k2 < 8; ++k2) {
-        pa[FT * 25 * k2] = pk0[k2];
-        pb[FT * 25 * k2] = pm0[k2];
+      for (int k2 = 0; k2 < 8; ++k2) pa[FT * 25 * k2] = pw[k2];
+      pb[0] = pw[8];
+      if (t != 0) {  // butterfly 0 repeats bins 175, 150, ... it already wrote
+#pragma unroll
+        for (int k2 = 9; k2 < 16; ++k2) pb[-FT * 25 * (k2 - 8)] = pw[k2];
       }
-    }
-    if (a1k > 0) {
-      float* __restrict__ pa = P + FT * a1k + lane;
-      float* __restrict__ pb = P + FT * (25 - a1k) + lane;
-#pragma unroll
-      for (int k2 = 0; k2 < 8; ++k2) {
-        pa[FT * 25 * k2] = pk1[k2];
-        pb[FT * 25 * k2] = pm1[k2];
-      }
-    } else if (a1k == 0) {
-      float* __restrict__ pz = P + lane;
-#pragma unroll
-      for (int k2 = 0; k2 < 5; ++k2) pz[FT * 25 * k2] = pk1[k2];
-#pragma unroll
-      for (int k2 = 0; k2 < 4; ++k2) pz[FT * (200 - 25 * k2)] = pm1[k2];
     }
     STAMP(13)
+    }
     __syncthreads();
     STAMP(14)
 
@@ -285,59 +299,11 @@ __global__ __launch_bounds__(w400::WG, 4) void logmel400_kernel(
       const bool valid = f0 + lane < p.F;
       // wave-uniform row pointer + lane offset: the row step is scalar arithmetic
       float* __restrict__ rowp = g_out + ((b * p.n_mels + m0) * p.F + f0);
-      const float* __restrict__ pr = P + FT * klo + lane;
-      float acc_cur = 0.0f, acc_next = 0.0f;
       float vmax = -INFINITY, vmin = INFINITY;
-      auto emit = [&]() {  // the filter in progress is complete
-        float outv = acc_cur;
-        if (EPI == MIA_EPI_WHISPER) {
-          // (log10(max(x, 1e-10)) + 4) / 4 as one FMA on log2
-          outv = fmaf(__builtin_amdgcn_logf(fmaxf(acc_cur, 1e-10f)), 0.25f * 0.30102999566f, 1.0f);
-        } else if (EPI == MIA_EPI_DB) {
-          // coef * log10(max(x, amin) / ref)
-          outv = fmaf(__builtin_amdgcn_logf(fmaxf(acc_cur, p.amin)), p.coef * 0.30102999566f,
-                      p.db_floor_shift);
-        }
-        if (EPI != MIA_EPI_NONE) {
-          vmax = fmaxf(vmax, outv);
-          vmin = fminf(vmin, outv);
-        }
-        if (valid) rowp[lane] = outv;
-        rowp += p.F;
-        acc_cur = acc_next;
-        acc_next = 0.0f;
-      };
-      for (int e = 0; e < npre; ++e) emit();
-      if (nchunks > 0) {
-        float4 wa0 = prog[0], wa1 = prog[1], wb0 = prog[2], wb1 = prog[3];
-        unsigned ctrl = __builtin_bit_cast(unsigned, prog[4].x);
-        float pv[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) pv[j] = pr[FT * j];
-        for (int c = 0; c < nchunks; ++c) {
-          const float4 ca0 = wa0, ca1 = wa1, cb0 = wb0, cb1 = wb1;
-          const unsigned cc = ctrl;
-          float cv[8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) cv[j] = pv[j];
-          {  // next chunk's record and power values, in flight during this chunk's FMAs
-            const int cn = c + 1 < nchunks ? c + 1 : c;
-            const float4* __restrict__ rn = prog + cn * (MEL_REC / 4);
-            wa0 = rn[0]; wa1 = rn[1]; wb0 = rn[2]; wb1 = rn[3];
-            ctrl = __builtin_bit_cast(unsigned, rn[4].x);
-            const float* __restrict__ qn = pr + FT * 8 * cn;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) pv[j] = qn[FT * j];
-          }
-          const float wa[8] = {ca0.x, ca0.y, ca0.z, ca0.w, ca1.x, ca1.y, ca1.z, ca1.w};
-          const float wb[8] = {cb0.x, cb0.y, cb0.z, cb0.w, cb1.x, cb1.y, cb1.z, cb1.w};
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            acc_cur = fmaf(wa[j], cv[j], acc_cur);
-            acc_next = fmaf(wb[j], cv[j], acc_next);
-            for (unsigned n = (cc >> (4 * j)) & 15u; n > 0; --n) emit();
-          }
-        }
+      if (f0 + FT <= p.F) {
+        mel_sweep<EPI, true>(p, P, prog, klo, nchunks, npre, rowp, lane, true, vmax, vmin);
+      } else {
+        mel_sweep<EPI, false>(p, P, prog, klo, nchunks, npre, rowp, lane, valid, vmax, vmin);
       }
 
       if (EPI != MIA_EPI_NONE && g_maxkey != nullptr) {
@@ -385,15 +351,15 @@ int launch_logmel400(const FwdParams& p0, const W400Tables& tb, hipStream_t s) {
   grid = (total + p.tiles_per_wg - 1) / p.tiles_per_wg;
   if (p.epi == MIA_EPI_WHISPER) {
     hipLaunchKernelGGL(logmel400_kernel<MIA_EPI_WHISPER>, dim3((unsigned)grid), dim3(w400::WG), 0,
-                       s, p, p.y, p.win, tb.tw2, tb.tws, tb.sweep_meta, tb.sweep_w, p.mout,
+                       s, p, p.y, tb.win16, tb.tw16, tb.sweep_meta, tb.sweep_w, p.mout,
                        p.clip_max_key, p.clip_min_key);
   } else if (p.epi == MIA_EPI_DB) {
     hipLaunchKernelGGL(logmel400_kernel<MIA_EPI_DB>, dim3((unsigned)grid), dim3(w400::WG), 0, s,
-                       p, p.y, p.win, tb.tw2, tb.tws, tb.sweep_meta, tb.sweep_w, p.mout,
+                       p, p.y, tb.win16, tb.tw16, tb.sweep_meta, tb.sweep_w, p.mout,
                        p.clip_max_key, p.clip_min_key);
   } else {
     hipLaunchKernelGGL(logmel400_kernel<MIA_EPI_NONE>, dim3((unsigned)grid), dim3(w400::WG), 0, s,
-                       p, p.y, p.win, tb.tw2, tb.tws, tb.sweep_meta, tb.sweep_w, p.mout,
+                       p, p.y, tb.win16, tb.tw16, tb.sweep_meta, tb.sweep_w, p.mout,
                        p.clip_max_key, p.clip_min_key);
   }
   MIA_CHECK_HIP(hipGetLastError());

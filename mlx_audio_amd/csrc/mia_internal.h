@@ -10,6 +10,11 @@
 
 #include "../../include/mia.h"
 
+// Shape of the n_fft = 400 / hop = 160 kernel's per-wave tables (logmel400.hip).
+#define W400_WAVES 16     /* waves (FFT roles) per workgroup */
+#define W400_MEL_MAXC 10  /* 8-bin chunks per wave, at most */
+#define W400_MEL_REC 32   /* dwords per chunk record: wA[8], wB[8], ctrl, pad */
+
 namespace mia {
 
 void set_error(const char* fmt, ...);
@@ -79,10 +84,10 @@ struct mia_plan {
   int n_mfcc = 0;
   float* d_dct = nullptr;        // n_mfcc x n_mels, rows pre-multiplied by the lifter
   // extra tables of the n_fft = 400 / hop = 160 kernel (null when not applicable)
-  float2* d_tw2 = nullptr;       // [25][8]  exp(-2 pi i t k1 / 200)
-  float2* d_tws = nullptr;       // [13][8]  exp(-2 pi i (k1 + 25 k2) / 400)
-  int* d_sweep_meta = nullptr;   // [8][16] per-wave sweep header: first bin, chunks, first filter
-  float* d_sweep_w = nullptr;    // [8][13][32] per-wave sweep program (see logmel400.hip)
+  float* d_win16 = nullptr;      // [16][32] window taps t + 16 r of role t (25 used)
+  float2* d_tw16 = nullptr;      // [16][16] exp(-2 pi i t k1 / 400), k1 = 0..12 used
+  int* d_sweep_meta = nullptr;   // [16][16] per-wave sweep header: first bin, chunks, first filter, pre-emits
+  float* d_sweep_w = nullptr;    // [16][W400_MEL_MAXC][32] per-wave sweep program (see logmel400.hip)
 };
 
 namespace mia {
@@ -114,8 +119,8 @@ struct FwdParams {
 };
 
 struct W400Tables {
-  const float2* tw2;
-  const float2* tws;
+  const float* win16;
+  const float2* tw16;
   const int* sweep_meta;
   const float* sweep_w;
 };

@@ -6,7 +6,7 @@ from mlx_audio_amd import _lib
 from mlx_audio_amd.frontends import compute_log_mel_spectrogram
 lib = _lib.lib()
 lib.mia_debug_set_buffer.argtypes = [ctypes.c_void_p]
-buf = torch.zeros(4 * 8 * 16, dtype=torch.int64, device="cuda")
+buf = torch.zeros(4 * 16 * 16, dtype=torch.int64, device="cuda")
 y = torch.randn((1024, 480000), device="cuda")
 for _ in range(3):
     compute_log_mel_spectrogram(y, n_mels=128, per_clip=True)
@@ -14,9 +14,9 @@ torch.cuda.synchronize()
 lib.mia_debug_set_buffer(buf.data_ptr())
 compute_log_mel_spectrogram(y, n_mels=128, per_clip=True)
 torch.cuda.synchronize()
-d = buf.cpu().numpy().reshape(4, 8, 16)
+d = buf.cpu().numpy().reshape(4, 16, 16)
 t00 = d[0, :, 0].min()
 for itn in range(4):
     print("iter", itn)
-    for w in range(8):
+    for w in range(16):
         print("  wave", w, " ".join("%6d" % (d[itn, w, i] - t00) for i in range(16)))
