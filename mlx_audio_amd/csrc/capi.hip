@@ -623,7 +623,9 @@ static int mel_forward(const mia_plan* plan, const float* y, int64_t B, int64_t 
     p.clip_max_key = max_keys;
     p.clip_min_key = min_keys;
   }
-  { const char* e = getenv("MIA_DBG"); p.dbg = e ? atoi(e) : 0; }
+#ifdef MIA_DEBUG_HOOKS
+  { const char* e = getenv("MIA_DBG"); p.dbg = e ? atoi(e) : 0; }  // profiling builds only
+#endif
   rc = forward_mel_dispatch(plan, p, s);
   if (rc != MIA_OK) return rc;
   if (clamp && B > 0) {

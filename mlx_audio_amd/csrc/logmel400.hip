@@ -47,8 +47,16 @@ static_assert(LDS_DWORDS >= ((SPAN + HOP - 1) / HOP) * RS, "span fits");
 static_assert(LDS_DWORDS >= (BINS + 8) * FT, "power tile (+ zero rows) fits");
 }  // namespace w400
 
+// Profiling hooks, compiled in only with -DMIA_DEBUG_HOOKS (tools/abl.sh, tools/stamps.py):
+// FwdParams::dbg bit 1 skips the mel sweep, bit 4 the output stores, bit 8 enables the
+// per-phase cycle stamps of workgroup 77 (needs -DMIA_W400_STAMPS as well).
+#ifdef MIA_DEBUG_HOOKS
+#define MIA_DBG(p, bit) ((p).dbg & (bit))
 __device__ unsigned long long* g_dbgbuf = nullptr;
-#ifdef MIA_W400_STAMPS
+#else
+#define MIA_DBG(p, bit) 0
+#endif
+#if defined(MIA_DEBUG_HOOKS) && defined(MIA_W400_STAMPS)
 #define STAMP(i)                                                                          \
   if ((p.dbg & 8) && g_dbgbuf && blockIdx.x == 77 && (threadIdx.x & 63) == 0 && it < 4)    \
     g_dbgbuf[(it * 16 + (threadIdx.x >> 6)) * 16 + (i)] = __builtin_readcyclecounter();
@@ -86,7 +94,7 @@ __device__ __forceinline__ void mel_sweep(const FwdParams& p, const float* __res
       vmax = fmaxf(vmax, outv);
       vmin = fminf(vmin, outv);
     }
-    if ((FULL || valid) && !(p.dbg & 4)) rowp[lane] = outv;
+    if ((FULL || valid) && !MIA_DBG(p, 4)) rowp[lane] = outv;
     rowp += p.F;
     acc_cur = acc_next;
     acc_next = 0.0f;
@@ -159,11 +167,6 @@ __global__ __launch_bounds__(w400::WG, 8) void logmel400_kernel(
   int cur_b = first / p.tiles;             // clip and tile-in-clip of the current tile,
   int cur_tile = first - cur_b * p.tiles;  // advanced incrementally
 
-  if (((p.dbg & 16) && blockIdx.x >= gridDim.x / 2) || ((p.dbg & 32) && (blockIdx.x & 1))) {
-    __builtin_amdgcn_s_sleep(127);
-    if (p.dbg & 64) __builtin_amdgcn_s_sleep(127);
-  }
-
   int it = 0;
   for (int idx = first; idx < last; ++idx, ++it) {
     const long long b = cur_b;
@@ -216,7 +219,6 @@ __global__ __launch_bounds__(w400::WG, 8) void logmel400_kernel(
     STAMP(2)
 
     float* __restrict__ P = lds;  // power tile, bin-major: P[k][frame]
-    if (!(p.dbg & 128)) {
     // ---- pass 1: real radix-25 over x[t + 16 r] of this lane's frame, then the step
     // twiddle exp(-2 pi i t k1 / 400) --------------------------------------------------
     float2 y[13];
@@ -290,12 +292,11 @@ __global__ __launch_bounds__(w400::WG, 8) void logmel400_kernel(
       }
     }
     STAMP(13)
-    }
     __syncthreads();
     STAMP(14)
 
     // ---- mel sweep + log epilogue ---------------------------------------------------------
-    if (!(p.dbg & 1)) {
+    if (!MIA_DBG(p, 1)) {
       const bool valid = f0 + lane < p.F;
       // wave-uniform row pointer + lane offset: the row step is scalar arithmetic
       float* __restrict__ rowp = g_out + ((b * p.n_mels + m0) * p.F + f0);
@@ -329,9 +330,11 @@ __global__ __launch_bounds__(w400::WG, 8) void logmel400_kernel(
   }
 }
 
+#ifdef MIA_DEBUG_HOOKS
 extern "C" void mia_debug_set_buffer(void* ptr) {
   (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dbgbuf), &ptr, sizeof(ptr));
 }
+#endif
 
 int launch_logmel400(const FwdParams& p0, const W400Tables& tb, hipStream_t s) {
   FwdParams p = p0;

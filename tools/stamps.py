@@ -1,3 +1,5 @@
+# Per-phase cycle stamps of the Whisper kernel; needs the library built with
+# MIA_EXTRA_FLAGS="-DMIA_DEBUG_HOOKS -DMIA_W400_STAMPS" python mlx_audio_amd/csrc/build.py --force
 import os, sys, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["MIA_DBG"] = sys.argv[1] if len(sys.argv) > 1 else "8"
