@@ -253,10 +253,16 @@ __global__ __launch_bounds__(w400::WG, 8) void logmel400_kernel(
     STAMP(5)
     __syncthreads();
     STAMP(6)
-    // Every wave reads here (waves 7..15 overwrite the result after phase B), so
-    // that v is defined on all paths and never carried around the tile loop.
+    // Waves 0..6 take their butterfly's inputs now.  The others get placeholder
+    // values (register copies, overwritten after phase B) so that v is defined on
+    // every path and is never carried around the tile loop.
+    if (t < 7) {
 #pragma unroll
-    for (int q = 0; q < 16; ++q) v[q] = ex[exr + 7 * q];
+      for (int q = 0; q < 16; ++q) v[q] = ex[exr + 7 * q];
+    } else {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) v[q] = y[q < 13 ? q : 0];
+    }
     STAMP(7)
     __syncthreads();
     STAMP(8)
@@ -266,7 +272,7 @@ __global__ __launch_bounds__(w400::WG, 8) void logmel400_kernel(
     STAMP(9)
     __syncthreads();
     STAMP(10)
-    if (t >= 7) {  // waves 13..15 read along (stale but finite slots) and discard the result
+    if (t >= 7 && bfly) {
 #pragma unroll
       for (int q = 0; q < 16; ++q) v[q] = ex[exr + 7 * q];
     }
@@ -341,6 +347,10 @@ int launch_logmel400(const FwdParams& p0, const W400Tables& tb, hipStream_t s) {
   p.tiles = (int)((p.F + w400::FT - 1) / w400::FT);
   const long long total = p.B * p.tiles;
   if (total <= 0) return MIA_OK;
+  if (total >= (1LL << 31)) {
+    set_error("batch too large for one launch: %lld tiles (split the batch)", total);
+    return MIA_ERR_UNSUPPORTED;
+  }
   // Persistent grid: 2 workgroups per CU, each walking a contiguous run of
   // tiles (consecutive tiles of a clip share cache lines of the output rows,
   // so one workgroup - one L2 - writes both halves of each line).
