@@ -1,33 +1,37 @@
 // Fused mel front-end for n_fft = 400, hop = 160 (Whisper's framing):
 // pad + frame + window + 400-point real FFT + |X|^2 + mel band projection +
-// log epilogue in one persistent kernel; a 1024-thread workgroup walks a run of
-// 64-frame tiles.
+// log epilogue in one persistent kernel; a 1024-thread workgroup (one per CU)
+// walks a run of 64-frame tiles.
 //
-// Mapping.  LANE = frame, WAVE = role inside the FFT.  The real transform is
-// split 16 x 25 on the real samples themselves:
-//   pass 1: wave t (0..15) does, for its lane's frame, the REAL-input radix-25
-//           DFT of x[t + 16 r], r = 0..24 (bins 0..12; the rest are conjugates),
-//           and applies the step twiddle exp(-2 pi i t k1 / 400);
-//   pass 2: wave k1 (0..12) does the radix-16 butterfly over t, which yields
-//           X[k1 + 25 k2], k2 = 0..15.  Bins above 200 are the conjugates of
-//           bins 400 - k, so the 13 butterflies give every |X[k]|^2, k = 0..200,
-//           with no split step.
-// Because the role is wave-uniform every twiddle, window tap and LDS offset is
-// a scalar or an instruction immediate and all 64 lanes work.  Sixteen light
-// waves (<= 64 VGPRs) instead of eight heavy ones put 8 waves on every SIMD.
+// FFT.  The real transform is split 16 x 25 on the real samples themselves:
+//   pass 1: role t (0..15) computes the REAL-input radix-25 DFT of x[t + 16 r],
+//           r = 0..24 (bins 0..12; the rest are conjugates) and applies the step
+//           twiddle exp(-2 pi i t k1 / 400);
+//   pass 2: butterfly k1 (0..12) is the radix-16 DFT over the roles and yields
+//           X[k1 + 25 k2], k2 = 0..15.  Bins above 200 are the conjugates of bins
+//           400 - k, so the 13 butterflies give every |X[k]|^2, k = 0..200, with
+//           no split step.
+// A wave owns 4 frames: lane = 16 * frame + role.  The pass-1 -> pass-2 exchange
+// therefore stays inside the wave (its own LDS region, no workgroup barrier), and
+// the 16 waves run the whole FFT phase free of each other, so one wave's LDS
+// traffic overlaps another's arithmetic.  Window taps and twiddles are per-lane
+// constants kept in VGPRs.
 //
-// Mel stage.  Each bin k of a triangular filterbank feeds at most two
-// filters: the rising edge of filter s(k) and the falling edge of filter
-// s(k)-1.  Every wave owns a run of filters and sweeps their bins once in
-// chunks of 8: the chunk's weights and control word arrive by scalar loads
-// (two FMAs per bin with an SGPR operand), and a filter is emitted (log,
-// store, running max/min) when the control word says it is complete.
+// Mel stage (after a barrier, LANE = frame).  Each bin k of a triangular
+// filterbank feeds at most two filters: the rising edge of filter s(k) and the
+// falling edge of filter s(k)-1.  Every wave owns a run of filters and sweeps
+// their bins once in chunks of 8: the chunk's weights and control word arrive
+// by scalar loads (two FMAs per bin with an SGPR operand), and a filter is
+// emitted (log, store, running max/min) when the control word says it is
+// complete.
 //
-// LDS (one 57.9 KB buffer, reused three times per tile, 2 workgroups per CU):
-//   span : the tile's 10480 samples, rows of 160 samples at stride 161 dwords
-//   ex   : pass-1 -> pass-2 exchange in two phases (k1 = 0..6, then 7..12),
-//          per frame 16 roles x 7 complex, stride 226 dwords
-//   P    : power spectrum, bin-major [201 (+8 zero rows)][64]
+// LDS (153 KB, nothing overlaid across waves, two barriers per tile):
+//   span    : the tile's 10480 samples, rows of 160 samples at stride 176
+//   priv[w] : per wave 1668 dwords: first the exchange (4 frames x 16 roles x 13
+//             complex), then, once the wave has read it back, its 4 columns of
+//             the power spectrum P[bin][frame & 3] (+ 8 zero rows)
+// The next tile's samples are fetched into registers at the start of the FFT
+// phase and written to the span buffer right after the barrier that ends it.
 #include "fft_engine.h"
 #include "mia_internal.h"
 
@@ -39,12 +43,16 @@ constexpr int BINS = N / 2 + 1;              // 201
 constexpr int SPAN = (FT - 1) * HOP + N;     // 10480 samples per tile
 constexpr int SPAN4 = SPAN / 4;              // 2620 float4
 constexpr int NPRE = (SPAN4 + WG - 1) / WG;  // 3 float4 per thread
-constexpr int RS = 161;                      // span row stride (dwords), odd: conflict-free b32
-constexpr int ES = 226;                      // exchange stride per frame (dwords), 2 mod 4
-constexpr int LDS_DWORDS = FT * ES;          // 14464
-static_assert(NW == 16, "the FFT split is 16 x 25");
-static_assert(LDS_DWORDS >= ((SPAN + HOP - 1) / HOP) * RS, "span fits");
-static_assert(LDS_DWORDS >= (BINS + 8) * FT, "power tile (+ zero rows) fits");
+constexpr int RS = 176;                      // span row stride: 16 mod 32, so 2 frames x 16 roles
+                                             // of a half-wave hit 32 different banks
+constexpr int SPAN_DWORDS = ((SPAN + HOP - 1) / HOP) * RS;  // 66 rows
+constexpr int EXF = 16 * 26;                 // exchange dwords per frame: 16 roles x 13 complex
+constexpr int PW = 4 * EXF + 4;              // per-wave region, 4 mod 32: conflict-free mel reads
+constexpr int LDS_DWORDS = SPAN_DWORDS + NW * PW;
+static_assert(NW == 16, "16 waves x 4 frames");
+static_assert(EXF % 64 == 32, "frames 0/1 of a half-wave read opposite bank halves");
+static_assert(PW >= 4 * (BINS + 8), "power columns (+ zero rows) fit the wave's region");
+static_assert(LDS_DWORDS * 4 <= 160 * 1024, "LDS budget");
 }  // namespace w400
 
 // Profiling hooks, compiled in only with -DMIA_DEBUG_HOOKS (tools/abl.sh, tools/stamps.py):
@@ -78,7 +86,7 @@ __device__ __forceinline__ void mel_sweep(const FwdParams& p, const float* __res
                                           int npre, float* __restrict__ rowp, int lane, bool valid,
                                           float& vmax, float& vmin) {
   using namespace w400;
-  const float* __restrict__ pr = P + FT * klo + lane;
+  const float* __restrict__ pr = P + (lane >> 2) * PW + (lane & 3) + 4 * klo;
   float acc_cur = 0.0f, acc_next = 0.0f;
   auto emit = [&]() {  // the filter in progress is complete
     float outv = acc_cur;
@@ -105,7 +113,7 @@ __device__ __forceinline__ void mel_sweep(const FwdParams& p, const float* __res
   unsigned ctrl = __builtin_bit_cast(unsigned, prog[4].x);
   float pv[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) pv[j] = pr[FT * j];
+  for (int j = 0; j < 8; ++j) pv[j] = pr[4 * j];
   for (int c = 0; c < nchunks; ++c) {
     const float4 ca0 = wa0, ca1 = wa1, cb0 = wb0, cb1 = wb1;
     const unsigned cc = ctrl;
@@ -120,9 +128,9 @@ __device__ __forceinline__ void mel_sweep(const FwdParams& p, const float* __res
       wb0 = rn[2];
       wb1 = rn[3];
       ctrl = __builtin_bit_cast(unsigned, rn[4].x);
-      const float* __restrict__ qn = pr + FT * 8 * cn;
+      const float* __restrict__ qn = pr + 4 * 8 * cn;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) pv[j] = qn[FT * j];
+      for (int j = 0; j < 8; ++j) pv[j] = qn[4 * j];
     }
     const float wa[8] = {ca0.x, ca0.y, ca0.z, ca0.w, ca1.x, ca1.y, ca1.z, ca1.w};
     const float wb[8] = {cb0.x, cb0.y, cb0.z, cb0.w, cb1.x, cb1.y, cb1.z, cb1.w};
@@ -135,8 +143,38 @@ __device__ __forceinline__ void mel_sweep(const FwdParams& p, const float* __res
   }
 }
 
+// Write one tile's samples (fetched as float4) into the span buffer.
+__device__ __forceinline__ void span_store(float* __restrict__ span,
+                                           const float4 (&regs)[w400::NPRE], int tid) {
+  using namespace w400;
+#pragma unroll
+  for (int i = 0; i < NPRE; ++i) {
+    const int q = tid + i * WG;
+    if (q < SPAN4) *reinterpret_cast<float4*>(span + RS * (q / 40) + 4 * (q % 40)) = regs[i];
+  }
+}
+__device__ __forceinline__ void span_fetch(float4 (&regs)[w400::NPRE],
+                                           const float* __restrict__ src0, int tid) {
+  using namespace w400;
+  const float4* __restrict__ src = reinterpret_cast<const float4*>(src0);
+#pragma unroll
+  for (int i = 0; i < NPRE; ++i) {
+    const int q = tid + i * WG;
+    regs[i] = src[q < SPAN4 ? q : SPAN4 - 1];
+  }
+}
+// Edge tiles of a clip (padding, or a clip start that is not 16-byte aligned).
+__device__ __forceinline__ void span_slow(float* __restrict__ span, const float* __restrict__ yb,
+                                          long long T, long long s_begin, int pad_mode, int tid) {
+  using namespace w400;
+#pragma unroll 1
+  for (int s = tid; s < SPAN; s += WG) {
+    span[RS * (s / HOP) + (s % HOP)] = fetch_sample(yb, T, s_begin + s, pad_mode);
+  }
+}
+
 template <int EPI>
-__global__ __launch_bounds__(w400::WG, 8) void logmel400_kernel(
+__global__ __launch_bounds__(w400::WG, 4) void logmel400_kernel(
     FwdParams p, const float* __restrict__ g_y, const float* __restrict__ g_win,
     const float2* __restrict__ g_tw, const int* __restrict__ g_meta,
     const float* __restrict__ g_sw, float* __restrict__ g_out, int* __restrict__ g_maxkey,
@@ -146,26 +184,53 @@ __global__ __launch_bounds__(w400::WG, 8) void logmel400_kernel(
   // the compiler must assume they alias the output and falls back to vector loads.
   using namespace w400;
   __shared__ __attribute__((aligned(16))) float lds[LDS_DWORDS];
+  float* __restrict__ span = lds;
+  float* __restrict__ P = lds + SPAN_DWORDS;  // the 16 per-wave regions
 
   const int tid0 = threadIdx.x;
-  const int t = __builtin_amdgcn_readfirstlane(tid0 >> 6);  // role
+  const int wv = __builtin_amdgcn_readfirstlane(tid0 >> 6);  // wave: frames 4 wv .. 4 wv + 3
   const int total = (int)(p.B * p.tiles);  // launcher guarantees < 2^31
   const int first = (int)blockIdx.x * p.tiles_per_wg;
   const int last = min(first + p.tiles_per_wg, total);
   if (first >= last) return;
 
-  // ---- per-wave constants -------------------------------------------------------
-  const int* __restrict__ meta = g_meta + 16 * t;
+  // ---- mel sweep constants of this wave -------------------------------------------
+  const int* __restrict__ meta = g_meta + 16 * wv;
   const int klo = meta[0], nchunks = meta[1], m0 = meta[2], npre = meta[3];
-  // this wave's sweep program: one 32-dword record per 8-bin chunk
   const float4* __restrict__ prog =
-      reinterpret_cast<const float4*>(g_sw) + t * (W400_MEL_MAXC * W400_MEL_REC / 4);
-  const bool bfly = t < 13;             // this wave owns pass-2 butterfly k1 = t
-  const int bslot = t < 7 ? t : t - 7;  // its slot inside its exchange phase
+      reinterpret_cast<const float4*>(g_sw) + wv * (W400_MEL_MAXC * W400_MEL_REC / 4);
 
-  int tid = tid0, lane = tid0 & 63;
+  // ---- FFT constants of this lane's role: window taps t + 16 r and the step
+  // twiddles exp(-2 pi i t k / 400), held in VGPRs for the whole run of tiles -------
+  const int role0 = tid0 & 15;
+  float wnd[25];
+  float2 twd[13];
+#pragma unroll
+  for (int r = 0; r < 25; ++r) {
+    wnd[r] = g_win[32 * role0 + r];
+    asm volatile("" : "+v"(wnd[r]));  // opaque: never re-fetched inside the loop
+  }
+#pragma unroll
+  for (int k = 1; k < 13; ++k) {
+    twd[k] = g_tw[16 * role0 + k];
+    asm volatile("" : "+v"(twd[k].x), "+v"(twd[k].y));
+  }
+
   int cur_b = first / p.tiles;             // clip and tile-in-clip of the current tile,
   int cur_tile = first - cur_b * p.tiles;  // advanced incrementally
+
+  // ---- the first tile's samples ---------------------------------------------------------
+  {
+    const float* __restrict__ yb = g_y + (long long)cur_b * p.T;
+    const long long s_begin = (long long)cur_tile * (FT * HOP) - p.pad;
+    if (tile_interior(yb, s_begin, p.T)) {
+      float4 regs[NPRE];
+      span_fetch(regs, yb + s_begin, tid0);
+      span_store(span, regs, tid0);
+    } else {
+      span_slow(span, yb, p.T, s_begin, p.pad_mode, tid0);
+    }
+  }
 
   int it = 0;
   for (int idx = first; idx < last; ++idx, ++it) {
@@ -178,130 +243,90 @@ __global__ __launch_bounds__(w400::WG, 8) void logmel400_kernel(
     const long long f0 = (long long)tile * FT;
     // Re-derive the lane-dependent addresses every tile instead of keeping
     // loop-invariant VGPRs alive across the whole loop body.
-    tid = tid0;
-    asm volatile("" : "+v"(tid)::"memory");  // also keeps this tile's loads below this point
-    lane = tid & 63;
+    int tid = tid0;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63;
+    const int role = lane & 15;  // pass 1: role t; pass 2: butterfly k1
+    const int fi = lane >> 4;    // frame of the wave's four
     STAMP(0)
-
-    // ---- stage the tile's samples: global -> LDS, rows of 160 at stride 161 ---------
-    {
-      const float* __restrict__ yb = g_y + b * p.T;
-      const long long s_begin = f0 * HOP - p.pad;
-      if (tile_interior(yb, s_begin, p.T)) {
-        const float4* __restrict__ src = reinterpret_cast<const float4*>(yb + s_begin);
-        float4 now[NPRE];
-#pragma unroll
-        for (int i = 0; i < NPRE; ++i) {
-          const int q = tid + i * WG;
-          now[i] = src[q < SPAN4 ? q : SPAN4 - 1];
-        }
-#pragma unroll
-        for (int i = 0; i < NPRE; ++i) {
-          const int q = tid + i * WG;
-          if (q < SPAN4) {
-            float* dst = lds + RS * (q / 40) + 4 * (q % 40);
-            dst[0] = now[i].x;
-            dst[1] = now[i].y;
-            dst[2] = now[i].z;
-            dst[3] = now[i].w;
-          }
-        }
-      } else {
-        // edge tiles of a clip (padding, or a clip start that is not 16-byte aligned)
-#pragma unroll 1
-        for (int s = tid; s < SPAN; s += WG) {
-          lds[RS * (s / HOP) + (s % HOP)] = fetch_sample(yb, p.T, s_begin + s, p.pad_mode);
-        }
-      }
-    }
+    __syncthreads();  // this tile's samples are staged; every wave has finished the previous mel sweep
     STAMP(1)
-    __syncthreads();
-    STAMP(2)
 
-    float* __restrict__ P = lds;  // power tile, bin-major: P[k][frame]
-    // ---- pass 1: real radix-25 over x[t + 16 r] of this lane's frame, then the step
-    // twiddle exp(-2 pi i t k1 / 400) --------------------------------------------------
-    float2 y[13];
+    // ---- fetch the next tile's samples; they land during the FFT phase --------------------
+    float4 regs[NPRE];
+    const bool more = idx + 1 < last;
+    const float* __restrict__ ynb = g_y + (long long)cur_b * p.T;  // cur_* already advanced
+    const long long sn = (long long)cur_tile * (FT * HOP) - p.pad;
+    const bool fast = more && tile_interior(ynb, sn, p.T);
+#pragma unroll
+    for (int i = 0; i < NPRE; ++i) regs[i] = {0.0f, 0.0f, 0.0f, 0.0f};  // defined on every path
+    if (fast) span_fetch(regs, ynb + sn, tid);
+
+    float* __restrict__ mine = P + wv * PW;  // this wave's exchange / power region
+    // ---- pass 1: real radix-25 over x[t + 16 r] of frame 4 wv + fi, then the step twiddle --
     {
-      const float* __restrict__ sp = lds + RS * lane + t;
-      const float* __restrict__ wt = g_win + 32 * t;  // taps t + 16 r, r = 0..24
+      float2 y[13];
+      const float* __restrict__ sp = span + RS * (4 * wv + fi) + role;
       float x[25];
 #pragma unroll
-      for (int r = 0; r < 25; ++r) x[r] = sp[16 * r + r / 10] * wt[r];
+      for (int r = 0; r < 25; ++r) x[r] = sp[16 * r + (RS - HOP) * (r / 10)] * wnd[r];
       rdft25(x, y);
-      const float2* __restrict__ tw = g_tw + 16 * t;
 #pragma unroll
-      for (int k = 1; k < 13; ++k) y[k] = cmul(y[k], tw[k]);
-      // All 13 outputs are final here: without this the scheduler sinks the second
-      // half of the transform below the exchange barriers, where its temporaries
-      // collide with the 16 pass-2 inputs.
+      for (int k = 1; k < 13; ++k) y[k] = cmul(y[k], twd[k]);
+      float2* __restrict__ exw = reinterpret_cast<float2*>(mine + EXF * fi + 26 * role);
 #pragma unroll
-      for (int k = 0; k < 13; ++k) asm volatile("" : "+v"(y[k].x), "+v"(y[k].y));
+      for (int c = 0; c < 13; ++c) exw[c] = y[c];
     }
-    STAMP(3)
-    __syncthreads();  // all span reads done; the buffer becomes the exchange area
-    STAMP(4)
+    STAMP(2)
+    // The exchange is private to the wave: LDS operations of one wave complete in
+    // order, so only the compiler has to be kept from moving them.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 
-    float2* __restrict__ ex = reinterpret_cast<float2*>(lds);
-    const int exw = (ES * lane + 14 * t) / 2;  // this thread's 7 exchange slots
-    const int exr = (ES * lane) / 2 + bslot;   // pass-2 reads: + 7 * t'
-    float2 v[16];
-
-    // phase A: outputs k1 = 0..6
-#pragma unroll
-    for (int c = 0; c < 7; ++c) ex[exw + c] = y[c];
-    STAMP(5)
-    __syncthreads();
-    STAMP(6)
-    // Waves 0..6 take their butterfly's inputs now.  The others get placeholder
-    // values (register copies, overwritten after phase B) so that v is defined on
-    // every path and is never carried around the tile loop.
-    if (t < 7) {
-#pragma unroll
-      for (int q = 0; q < 16; ++q) v[q] = ex[exr + 7 * q];
-    } else {
-#pragma unroll
-      for (int q = 0; q < 16; ++q) v[q] = y[q < 13 ? q : 0];
-    }
-    STAMP(7)
-    __syncthreads();
-    STAMP(8)
-    // phase B: outputs k1 = 7..12 at slot k1 - 7
-#pragma unroll
-    for (int c = 0; c < 6; ++c) ex[exw + c] = y[7 + c];
-    STAMP(9)
-    __syncthreads();
-    STAMP(10)
-    if (t >= 7 && bfly) {
-#pragma unroll
-      for (int q = 0; q < 16; ++q) v[q] = ex[exr + 7 * q];
-    }
-    // ---- pass 2: radix-16 over the roles; v[k2] = X[t + 25 k2] -----------------------
+    // ---- pass 2: radix-16 over the roles; v[k2] = X[k1 + 25 k2] (lanes k1 = 13..15 idle along) --
     float pw[16];
-    Dft<16>::run(v);
+    {
+      float2 v[16];
+      const int k1r = role < 13 ? role : 12;
+      const float2* __restrict__ exr = reinterpret_cast<const float2*>(mine + EXF * fi + 2 * k1r);
 #pragma unroll
-    for (int k2 = 0; k2 < 16; ++k2) pw[k2] = fmaf(v[k2].x, v[k2].x, v[k2].y * v[k2].y);
-    STAMP(11)
-    __syncthreads();  // exchange reads done; the buffer becomes the power tile
-    STAMP(12)
+      for (int q = 0; q < 16; ++q) v[q] = exr[13 * q];
+      Dft<16>::run(v);
+#pragma unroll
+      for (int k2 = 0; k2 < 16; ++k2) pw[k2] = fmaf(v[k2].x, v[k2].x, v[k2].y * v[k2].y);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    STAMP(3)
 
-    if (tid < 512) P[FT * BINS + tid] = 0.0f;  // rows 201..208: read (zero weight) by a padded chunk
-    if (bfly) {
-      float* __restrict__ pa = P + FT * t + lane;          // bins t + 25 k2, k2 = 0..7
-      float* __restrict__ pb = P + FT * (200 - t) + lane;  // bins 400 - (t + 25 k2), k2 = 8..15
+    // ---- power columns of the wave's 4 frames: mine[4 * bin + fi] ---------------------------
+    if (lane < 32) mine[4 * BINS + lane] = 0.0f;  // bins 201..208: read (zero weight) by a padded chunk
+    if (role < 13) {
+      float* __restrict__ pa = mine + 4 * role + fi;          // bins k1 + 25 k2, k2 = 0..7
+      float* __restrict__ pb = mine + 4 * (200 - role) + fi;  // bins 400 - (k1 + 25 k2), k2 = 8..15
 #pragma unroll
-      for (int k2 = 0; k2 < 8; ++k2) pa[FT * 25 * k2] = pw[k2];
+      for (int k2 = 0; k2 < 8; ++k2) pa[4 * 25 * k2] = pw[k2];
       pb[0] = pw[8];
-      if (t != 0) {  // butterfly 0 repeats bins 175, 150, ... it already wrote
+      if (role != 0) {  // butterfly 0 repeats bins 175, 150, ... it already wrote
 #pragma unroll
-        for (int k2 = 9; k2 < 16; ++k2) pb[-FT * 25 * (k2 - 8)] = pw[k2];
+        for (int k2 = 9; k2 < 16; ++k2) pb[-4 * 25 * (k2 - 8)] = pw[k2];
       }
     }
-    STAMP(13)
-    __syncthreads();
-    STAMP(14)
+    STAMP(4)
+    __syncthreads();  // the power tile is complete; nobody reads the span buffer any more
+    STAMP(5)
 
-    // ---- mel sweep + log epilogue ---------------------------------------------------------
+    // ---- stage the next tile --------------------------------------------------------------
+    if (fast) {
+      span_store(span, regs, tid);
+    } else if (more) {
+      span_slow(span, ynb, p.T, sn, p.pad_mode, tid);
+    }
+    STAMP(6)
+
+    // ---- mel sweep + log epilogue (lane = frame) --------------------------------------------
     if (!MIA_DBG(p, 1)) {
       const bool valid = f0 + lane < p.F;
       // wave-uniform row pointer + lane offset: the row step is scalar arithmetic
@@ -331,8 +356,7 @@ __global__ __launch_bounds__(w400::WG, 8) void logmel400_kernel(
         }
       }
     }
-    STAMP(15)
-    __syncthreads();  // power tile reads done before the next tile is staged
+    STAMP(7)
   }
 }
 
@@ -351,14 +375,14 @@ int launch_logmel400(const FwdParams& p0, const W400Tables& tb, hipStream_t s) {
     set_error("batch too large for one launch: %lld tiles (split the batch)", total);
     return MIA_ERR_UNSUPPORTED;
   }
-  // Persistent grid: 2 workgroups per CU, each walking a contiguous run of
-  // tiles (consecutive tiles of a clip share cache lines of the output rows,
-  // so one workgroup - one L2 - writes both halves of each line).
+  // Persistent grid: one workgroup per CU (153 KB of LDS), each walking a
+  // contiguous run of tiles (consecutive tiles of a clip share cache lines of the
+  // output rows, so one workgroup - one L2 - writes both halves of each line).
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) == hipSuccess) {
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   }
-  long long grid = 2LL * cus;
+  long long grid = 1LL * cus;
   if (grid > total) grid = total;
   p.tiles_per_wg = (int)((total + grid - 1) / grid);
   grid = (total + p.tiles_per_wg - 1) / p.tiles_per_wg;
