@@ -267,7 +267,7 @@ static int build_w400_tables(mia_plan* p, const float* window, const float* basi
   auto cost = [&](int m0, int m1) {  // filters [m0, m1)
     int klo = 0;
     const int nb = bins_of(m0, m1, klo);
-    return 7.0 * (m1 - m0) + 2.0 * nb + 10.0 * ((nb + kChunk - 1) / kChunk);
+    return 12.0 * (m1 - m0) + 9.0 * nb + 80.0 * ((nb + kChunk - 1) / kChunk);
   };
   auto deal = [&](double bound, int* starts) {
     int m = 0;
