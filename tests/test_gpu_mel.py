@@ -229,3 +229,33 @@ def test_clap_features(gpu):
     for c in range(1, 4):  # each crop is a contiguous window of the full mel
         d = [np.abs(full[s:s + 1001] - crops[c]).max() for s in range(full.shape[0] - 1000)]
         assert min(d) <= 1e-3
+
+
+@pytest.mark.parametrize("T", [400, 401, 1000, 10239, 10240, 10241, 16001, 20479, 20483])
+def test_logmel_whisper_awkward_lengths(gpu, T):
+    """Clip lengths around the 64-frame tile size, odd lengths (clips after the first are then
+    not 16-byte aligned, which takes the per-sample staging path) and clips shorter than a tile."""
+    from mlx_audio_amd.frontends import compute_log_mel_spectrogram
+
+    rng = np.random.default_rng(T)
+    x = rng.standard_normal((3, T)).astype(np.float32)
+    got = compute_log_mel_spectrogram(torch.from_numpy(x).to(gpu), n_mels=80, per_clip=True)
+    assert tuple(got.shape) == (3, 80, 1 + T // 160)
+    got = got.cpu().numpy()
+    for b in range(3):
+        ref = o.compute_log_mel_spectrogram(x[b], n_mels=80)
+        assert np.abs(got[b] - ref).max() <= 1e-4, (T, b)
+
+
+def test_logmel_whisper_unswept_filterbank_uses_generic_kernel(gpu):
+    """A filterbank that is not of the two-taps-per-bin triangular form (here: power 1.0, and a
+    filterbank with fmax below Nyquist and HTK spacing) must still match the oracle."""
+    from mlx_audio_amd.primitives import melspectrogram
+
+    rng = np.random.default_rng(77)
+    x = rng.standard_normal((2, 16000)).astype(np.float32)
+    for kw in (dict(power=1.0), dict(htk=True, fmin=100.0, fmax=6000.0, n_mels=40),
+               dict(norm=None, n_mels=20)):
+        got = melspectrogram(torch.from_numpy(x).to(gpu), sr=16000, n_fft=400, hop_length=160, **kw)
+        ref = o.melspectrogram(x, sr=16000, n_fft=400, hop_length=160, **kw)
+        np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=1e-4, atol=1e-5 * ref.max())
