@@ -72,12 +72,16 @@ __device__ unsigned long long* g_dbgbuf = nullptr;
 #define STAMP(i)
 #endif
 
-// A tile whose samples all lie inside the clip (no padding) and start on a
-// 16-byte boundary can be fetched as float4.
+// A tile whose samples all lie inside the clip (no padding) is fetched four
+// samples per lane.  Clips need not start on a 16-byte boundary (odd clip
+// lengths): the vector type below only promises float alignment.
 __device__ __forceinline__ bool tile_interior(const float* yb, long long s_begin, long long T) {
-  return s_begin >= 0 && s_begin + w400::SPAN <= T &&
-         ((reinterpret_cast<uintptr_t>(yb + s_begin) & 15) == 0);
+  (void)yb;
+  return s_begin >= 0 && s_begin + w400::SPAN <= T;
 }
+struct __attribute__((packed, aligned(4))) float4_a4 {
+  float x, y, z, w;
+};
 
 // Mel sweep of one wave over the power tile.  FULL: every lane's frame exists.
 template <int EPI, bool FULL>
@@ -156,11 +160,12 @@ __device__ __forceinline__ void span_store(float* __restrict__ span,
 __device__ __forceinline__ void span_fetch(float4 (&regs)[w400::NPRE],
                                            const float* __restrict__ src0, int tid) {
   using namespace w400;
-  const float4* __restrict__ src = reinterpret_cast<const float4*>(src0);
+  const float4_a4* __restrict__ src = reinterpret_cast<const float4_a4*>(src0);
 #pragma unroll
   for (int i = 0; i < NPRE; ++i) {
     const int q = tid + i * WG;
-    regs[i] = src[q < SPAN4 ? q : SPAN4 - 1];
+    const float4_a4 v = src[q < SPAN4 ? q : SPAN4 - 1];
+    regs[i] = {v.x, v.y, v.z, v.w};
   }
 }
 // Edge tiles of a clip (padding, or a clip start that is not 16-byte aligned).
