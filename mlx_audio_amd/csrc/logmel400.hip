@@ -72,13 +72,8 @@ __device__ unsigned long long* g_dbgbuf = nullptr;
 #define STAMP(i)
 #endif
 
-// A tile whose samples all lie inside the clip (no padding) is fetched four
-// samples per lane.  Clips need not start on a 16-byte boundary (odd clip
-// lengths): the vector type below only promises float alignment.
-__device__ __forceinline__ bool tile_interior(const float* yb, long long s_begin, long long T) {
-  (void)yb;
-  return s_begin >= 0 && s_begin + w400::SPAN <= T;
-}
+// Four consecutive samples.  Clips need not start on a 16-byte boundary (odd clip
+// lengths): the type only promises float alignment.
 struct __attribute__((packed, aligned(4))) float4_a4 {
   float x, y, z, w;
 };
@@ -157,24 +152,23 @@ __device__ __forceinline__ void span_store(float* __restrict__ span,
     if (q < SPAN4) *reinterpret_cast<float4*>(span + RS * (q / 40) + 4 * (q % 40)) = regs[i];
   }
 }
-__device__ __forceinline__ void span_fetch(float4 (&regs)[w400::NPRE],
-                                           const float* __restrict__ src0, int tid) {
+// Fetch this thread's share of a tile's 10480 samples, four per register quad.
+// Quads that lie wholly inside the clip are one vector load; the few that touch
+// a clip boundary go sample by sample through the padding rule.
+__device__ __forceinline__ void span_fetch(float4 (&regs)[w400::NPRE], const float* __restrict__ yb,
+                                           long long T, long long s_begin, int pad_mode, int tid) {
   using namespace w400;
-  const float4_a4* __restrict__ src = reinterpret_cast<const float4_a4*>(src0);
 #pragma unroll
   for (int i = 0; i < NPRE; ++i) {
     const int q = tid + i * WG;
-    const float4_a4 v = src[q < SPAN4 ? q : SPAN4 - 1];
-    regs[i] = {v.x, v.y, v.z, v.w};
-  }
-}
-// Edge tiles of a clip (padding, or a clip start that is not 16-byte aligned).
-__device__ __forceinline__ void span_slow(float* __restrict__ span, const float* __restrict__ yb,
-                                          long long T, long long s_begin, int pad_mode, int tid) {
-  using namespace w400;
-#pragma unroll 1
-  for (int s = tid; s < SPAN; s += WG) {
-    span[RS * (s / HOP) + (s % HOP)] = fetch_sample(yb, T, s_begin + s, pad_mode);
+    const long long s0 = s_begin + 4 * (q < SPAN4 ? q : SPAN4 - 1);
+    if (s0 >= 0 && s0 + 4 <= T) {
+      const float4_a4 v = *reinterpret_cast<const float4_a4*>(yb + s0);
+      regs[i] = {v.x, v.y, v.z, v.w};
+    } else {
+      regs[i] = {fetch_sample(yb, T, s0, pad_mode), fetch_sample(yb, T, s0 + 1, pad_mode),
+                 fetch_sample(yb, T, s0 + 2, pad_mode), fetch_sample(yb, T, s0 + 3, pad_mode)};
+    }
   }
 }
 
@@ -228,13 +222,9 @@ __global__ __launch_bounds__(w400::WG, 4) void logmel400_kernel(
   {
     const float* __restrict__ yb = g_y + (long long)cur_b * p.T;
     const long long s_begin = (long long)cur_tile * (FT * HOP) - p.pad;
-    if (tile_interior(yb, s_begin, p.T)) {
-      float4 regs[NPRE];
-      span_fetch(regs, yb + s_begin, tid0);
-      span_store(span, regs, tid0);
-    } else {
-      span_slow(span, yb, p.T, s_begin, p.pad_mode, tid0);
-    }
+    float4 regs[NPRE];
+    span_fetch(regs, yb, p.T, s_begin, p.pad_mode, tid0);
+    span_store(span, regs, tid0);
   }
 
   int it = 0;
@@ -262,10 +252,9 @@ __global__ __launch_bounds__(w400::WG, 4) void logmel400_kernel(
     const bool more = idx + 1 < last;
     const float* __restrict__ ynb = g_y + (long long)cur_b * p.T;  // cur_* already advanced
     const long long sn = (long long)cur_tile * (FT * HOP) - p.pad;
-    const bool fast = more && tile_interior(ynb, sn, p.T);
 #pragma unroll
     for (int i = 0; i < NPRE; ++i) regs[i] = {0.0f, 0.0f, 0.0f, 0.0f};  // defined on every path
-    if (fast) span_fetch(regs, ynb + sn, tid);
+    if (more) span_fetch(regs, ynb, p.T, sn, p.pad_mode, tid);
 
     float* __restrict__ mine = P + wv * PW;  // this wave's exchange / power region
     // ---- pass 1: real radix-25 over x[t + 16 r] of frame 4 wv + fi, then the step twiddle --
@@ -324,11 +313,7 @@ __global__ __launch_bounds__(w400::WG, 4) void logmel400_kernel(
     STAMP(5)
 
     // ---- stage the next tile --------------------------------------------------------------
-    if (fast) {
-      span_store(span, regs, tid);
-    } else if (more) {
-      span_slow(span, ynb, p.T, sn, p.pad_mode, tid);
-    }
+    if (more) span_store(span, regs, tid);
     STAMP(6)
 
     // ---- mel sweep + log epilogue (lane = frame) --------------------------------------------
