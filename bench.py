@@ -147,8 +147,8 @@ def cpu_baseline(budget_s: float = 12.0) -> dict:
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="whisper128")
     ap.add_argument("--clips", type=int, default=None, help="clips (rows) per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -9,7 +9,7 @@ mkdir -p "$out"
 export TMPDIR=/tmp
 cd /tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- \
-  python3 "$root/bench.py" --steps 10 --warmup 2 --no-cpu-baseline > "$out/bench_trace.log" 2>&1 || exit 1
+  python3 "$root/bench.py" --no-cpu-baseline > "$out/bench_trace.log" 2>&1 || exit 1
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch" -- \
   python3 "$root/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > "$out/bench_fetch.log" 2>&1 || exit 1
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/pmc_write" -- \
