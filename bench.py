@@ -152,6 +152,8 @@ def main() -> None:
     ap.add_argument("--workload", default="whisper128")
     ap.add_argument("--clips", type=int, default=None, help="clips (rows) per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gather", action="store_true",
+                    help="also time one RCCL all-gather of the features to rank 0 (N > 1)")
     args = ap.parse_args()
 
     import torch
@@ -201,6 +203,18 @@ def main() -> None:
     barrier()
     elapsed = time.perf_counter() - t0
     dev_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
+    gather_ms = None
+    if args.gather and dist is not None and isinstance(out, torch.Tensor):
+        # Outside the headline number: the optional collection of the finished
+        # features on rank 0, one all-gather over xGMI.
+        from mlx_audio_amd.sharding import gather_features
+
+        gather_features(out, n_gpus * clips)  # warm-up (communicator set-up)
+        barrier()
+        tg = time.perf_counter()
+        gather_features(out, n_gpus * clips)
+        barrier()
+        gather_ms = max_over_ranks(time.perf_counter() - tg, device) * 1e3
     del out
     elapsed = max_over_ranks(elapsed, device)
 
@@ -236,6 +250,8 @@ def main() -> None:
                 "device_ms_per_step": dev_ms,
             },
         }
+        if gather_ms is not None:
+            line["gather_ms"] = gather_ms
         if n_gpus == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))
