@@ -78,6 +78,19 @@ struct __attribute__((packed, aligned(4))) float4_a4 {
   float x, y, z, w;
 };
 
+// v_max_f32 / v_min_f32 as the hardware defines them (a NaN operand loses to a
+// number).  fmaxf / fminf would put a canonicalising v_max x, x, x in front of each.
+__device__ __forceinline__ float max_raw(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float min_raw(float a, float b) {
+  float r;
+  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
 // Mel sweep of one wave over the power tile.  FULL: every lane's frame exists.
 template <int EPI, bool FULL>
 __device__ __forceinline__ void mel_sweep(const FwdParams& p, const float* __restrict__ P,
@@ -91,15 +104,15 @@ __device__ __forceinline__ void mel_sweep(const FwdParams& p, const float* __res
     float outv = acc_cur;
     if (EPI == MIA_EPI_WHISPER) {
       // (log10(max(x, 1e-10)) + 4) / 4 as one FMA on log2
-      outv = fmaf(__builtin_amdgcn_logf(fmaxf(acc_cur, 1e-10f)), 0.25f * 0.30102999566f, 1.0f);
+      outv = fmaf(__builtin_amdgcn_logf(max_raw(acc_cur, 1e-10f)), 0.25f * 0.30102999566f, 1.0f);
     } else if (EPI == MIA_EPI_DB) {
       // coef * log10(max(x, amin) / ref)
-      outv = fmaf(__builtin_amdgcn_logf(fmaxf(acc_cur, p.amin)), p.coef * 0.30102999566f,
+      outv = fmaf(__builtin_amdgcn_logf(max_raw(acc_cur, p.amin)), p.coef * 0.30102999566f,
                   p.db_floor_shift);
     }
-    if (EPI != MIA_EPI_NONE) {
-      vmax = fmaxf(vmax, outv);
-      vmin = fminf(vmin, outv);
+    if (EPI != MIA_EPI_NONE && (FULL || valid)) {
+      vmax = max_raw(vmax, outv);
+      vmin = min_raw(vmin, outv);
     }
     if ((FULL || valid) && !MIA_DBG(p, 4)) rowp[lane] = outv;
     rowp += p.F;
@@ -227,6 +240,9 @@ __global__ __launch_bounds__(w400::WG, 4) void logmel400_kernel(
     span_store(span, regs, tid0);
   }
 
+  // Running extremes of the clip this wave is in; they leave the wave (one atomic
+  // pair) only when the clip or the run of tiles ends.
+  float vmax = -INFINITY, vmin = INFINITY;
   int it = 0;
   for (int idx = first; idx < last; ++idx, ++it) {
     const long long b = cur_b;
@@ -321,29 +337,27 @@ __global__ __launch_bounds__(w400::WG, 4) void logmel400_kernel(
       const bool valid = f0 + lane < p.F;
       // wave-uniform row pointer + lane offset: the row step is scalar arithmetic
       float* __restrict__ rowp = g_out + ((b * p.n_mels + m0) * p.F + f0);
-      float vmax = -INFINITY, vmin = INFINITY;
       if (f0 + FT <= p.F) {
         mel_sweep<EPI, true>(p, P, prog, klo, nchunks, npre, rowp, lane, true, vmax, vmin);
       } else {
         mel_sweep<EPI, false>(p, P, prog, klo, nchunks, npre, rowp, lane, valid, vmax, vmin);
       }
 
-      if (EPI != MIA_EPI_NONE && g_maxkey != nullptr) {
-        if (!valid) {
-          vmax = -INFINITY;
-          vmin = INFINITY;
-        }
+      if (EPI != MIA_EPI_NONE && g_maxkey != nullptr && (cur_tile == 0 || !more)) {
+        float rmax = vmax, rmin = vmin;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
-          vmax = fmaxf(vmax, __shfl_xor(vmax, off));
-          vmin = fminf(vmin, __shfl_xor(vmin, off));
+          rmax = fmaxf(rmax, __shfl_xor(rmax, off));
+          rmin = fminf(rmin, __shfl_xor(rmin, off));
         }
         if (lane == 0) {
           // the max key is kept on the log10 scale (before the (.+4)/4 map)
-          if (EPI == MIA_EPI_WHISPER) vmax = fmaf(vmax, 4.0f, -4.0f);
-          atomicMax(g_maxkey + b, float_to_key(vmax));
-          atomicMin(g_minkey + b, float_to_key(vmin));
+          if (EPI == MIA_EPI_WHISPER) rmax = fmaf(rmax, 4.0f, -4.0f);
+          atomicMax(g_maxkey + b, float_to_key(rmax));
+          atomicMin(g_minkey + b, float_to_key(rmin));
         }
+        vmax = -INFINITY;
+        vmin = INFINITY;
       }
     }
     STAMP(7)
