@@ -578,9 +578,10 @@ extern "C" size_t mia_mel_workspace_bytes(const mia_plan* plan, int64_t B, int64
   return 2 * align256(sizeof(int) * (size_t)(B + 1));
 }
 
-// The lane-per-frame kernel when the plan has its tables, else the generic one.
+// The n_fft = 400 kernel when the plan has its tables (and a clip's output fits the
+// kernel's 32-bit offsets), else the generic one.
 static int forward_mel_dispatch(const mia_plan* plan, const FwdParams& p, hipStream_t s) {
-  if (plan->d_sweep_meta != nullptr) {
+  if (plan->d_sweep_meta != nullptr && p.n_mels * p.F < (1LL << 30)) {
     W400Tables tb{plan->d_win16, plan->d_tw16, plan->d_sweep_meta, plan->d_sweep_w};
     return launch_logmel400(p, tb, s);
   }

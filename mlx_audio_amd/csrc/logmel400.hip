@@ -11,27 +11,29 @@
 //           X[k1 + 25 k2], k2 = 0..15.  Bins above 200 are the conjugates of bins
 //           400 - k, so the 13 butterflies give every |X[k]|^2, k = 0..200, with
 //           no split step.
-// A wave owns 4 frames: lane = 16 * frame + role.  The pass-1 -> pass-2 exchange
-// therefore stays inside the wave (its own LDS region, no workgroup barrier), and
-// the 16 waves run the whole FFT phase free of each other, so one wave's LDS
-// traffic overlaps another's arithmetic.  Window taps and twiddles are per-lane
-// constants kept in VGPRs.
+// A wave owns 4 frames: lane = 16 * frame + role.  It loads the 880 samples under
+// the next tile's 4 frames as float4 while it transforms the current tile, and after
+// the mel sweep passes them through its own LDS region to the lanes that need them.
+// The pass-1 -> pass-2 exchange stays inside the wave too (no workgroup barrier).
+// Window taps and twiddles are per-lane constants kept in VGPRs.
 //
-// Mel stage (after a barrier, LANE = frame).  Each bin k of a triangular
-// filterbank feeds at most two filters: the rising edge of filter s(k) and the
-// falling edge of filter s(k)-1.  Every wave owns a run of filters and sweeps
-// their bins once in chunks of 8: the chunk's weights and control word arrive
-// by scalar loads (two FMAs per bin with an SGPR operand), and a filter is
-// emitted (log, store, running max/min) when the control word says it is
-// complete.
+// Mel stage (LANE = frame).  Each bin k of a triangular filterbank feeds at most
+// two filters: the rising edge of filter s(k) and the falling edge of filter
+// s(k)-1.  Every wave owns a run of filters and sweeps their bins once in chunks
+// of 8: the chunk's weights and control word arrive by scalar loads (two FMAs per
+// bin with an SGPR operand), and a filter is emitted (log, store, running
+// max/min) when the control word says it is complete.
 //
-// LDS (153 KB, nothing overlaid across waves, two barriers per tile):
-//   span    : the tile's 10480 samples, rows of 160 samples at stride 176
-//   priv[w] : per wave 1668 dwords: first the exchange (4 frames x 16 roles x 13
-//             complex), then, once the wave has read it back, its 4 columns of
-//             the power spectrum P[bin][frame & 3] (+ 8 zero rows)
-// The next tile's samples are fetched into registers at the start of the FFT
-// phase and written to the span buffer right after the barrier that ends it.
+// LDS (158 KB) and synchronisation.  Per wave: a power slot of 840 dwords, 832
+// dwords of scratch, and a second power slot.  The exchange of tile i lives in
+// slot[i & 1] (frames 0, 1) and the scratch (frames 2, 3); before that the same run
+// of LDS passes the tile's samples from the lanes that loaded them to the lanes that
+// transform them; once the wave has read the exchange back, its 4 columns of the
+// power spectrum P[bin][frame & 3] (+ 8 zero rows) replace the slot's contents.
+// The mel sweep of tile i reads slot[i & 1] of all 16 waves while waves that are done
+// with it already stage and transform tile i + 1 in the other slot, so ONE barrier
+// per tile (power of tile i complete = every wave is done with the sweep of tile
+// i - 1) is all the workgroup needs.
 #include "fft_engine.h"
 #include "mia_internal.h"
 
@@ -39,19 +41,22 @@ namespace mia {
 
 namespace w400 {
 constexpr int N = 400, HOP = 160, FT = 64, NW = W400_WAVES, WG = NW * 64;
-constexpr int BINS = N / 2 + 1;              // 201
-constexpr int SPAN = (FT - 1) * HOP + N;     // 10480 samples per tile
-constexpr int SPAN4 = SPAN / 4;              // 2620 float4
-constexpr int NPRE = (SPAN4 + WG - 1) / WG;  // 3 float4 per thread
-constexpr int RS = 176;                      // span row stride: 16 mod 32, so 2 frames x 16 roles
-                                             // of a half-wave hit 32 different banks
-constexpr int SPAN_DWORDS = ((SPAN + HOP - 1) / HOP) * RS;  // 66 rows
-constexpr int EXF = 16 * 26;                 // exchange dwords per frame: 16 roles x 13 complex
-constexpr int PW = 4 * EXF + 4;              // per-wave region, 4 mod 32: conflict-free mel reads
-constexpr int LDS_DWORDS = SPAN_DWORDS + NW * PW;
+constexpr int BINS = N / 2 + 1;   // 201
+constexpr int EXF = 16 * 26;      // exchange dwords per frame: 16 roles x 13 complex
+constexpr int SL = 840;           // power slot: 2 frames of exchange, then 4 x (201 + 8) power values
+constexpr int SC = 2 * EXF;       // scratch: the exchange of frames 2, 3
+constexpr int PW = 2 * SL + SC + 20;  // per-wave region, 4 mod 32: conflict-free mel reads
+constexpr int WSPAN = 3 * HOP + N;    // 880 samples under a wave's 4 frames
+constexpr int WQ = WSPAN / 4;         // 220 float4
+constexpr int NPRE = (WQ + 63) / 64;  // 4 float4 per lane
+constexpr int RS = 176;               // staged sample rows: 160 samples at stride 176 (16 mod 32), so
+                                      // 2 frames x 16 roles of a half-wave hit 32 different banks
+static_assert(RS * (WSPAN / HOP) + WSPAN % HOP <= SL + SC, "staged samples fit slot + scratch");
+constexpr int LDS_DWORDS = NW * PW;
 static_assert(NW == 16, "16 waves x 4 frames");
 static_assert(EXF % 64 == 32, "frames 0/1 of a half-wave read opposite bank halves");
-static_assert(PW >= 4 * (BINS + 8), "power columns (+ zero rows) fit the wave's region");
+static_assert(SL >= 2 * EXF && SL >= 4 * (BINS + 8) && SL % 2 == 0, "slot holds either content");
+static_assert(PW % 32 == 4, "mel reads of 16 waves' regions hit 64 different banks");
 static_assert(LDS_DWORDS * 4 <= 160 * 1024, "LDS budget");
 }  // namespace w400
 
@@ -72,23 +77,18 @@ __device__ unsigned long long* g_dbgbuf = nullptr;
 #define STAMP(i)
 #endif
 
-// Four consecutive samples.  Clips need not start on a 16-byte boundary (odd clip
-// lengths): the type only promises float alignment.
-struct __attribute__((packed, aligned(4))) float4_a4 {
-  float x, y, z, w;
-};
-
-// v_max_f32 / v_min_f32 as the hardware defines them (a NaN operand loses to a
-// number).  fmaxf / fminf would put a canonicalising v_max x, x, x in front of each.
-__device__ __forceinline__ float max_raw(float a, float b) {
-  float r;
-  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
+// max / min as one v_med3_f32 each (a NaN operand loses to a number): fmaxf / fminf
+// would put a canonicalising v_max x, x, x in front of every use.  The infinity comes
+// in as an opaque register so that the compiler cannot fold the median back into them.
+__device__ __forceinline__ float opaque_vgpr(float x) {
+  asm volatile("" : "+v"(x));
+  return x;
 }
-__device__ __forceinline__ float min_raw(float a, float b) {
-  float r;
-  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
+__device__ __forceinline__ float max_raw(float a, float b, float pinf) {
+  return __builtin_amdgcn_fmed3f(a, b, pinf);
+}
+__device__ __forceinline__ float min_raw(float a, float b, float ninf) {
+  return __builtin_amdgcn_fmed3f(a, b, ninf);
 }
 
 // Mel sweep of one wave over the power tile.  FULL: every lane's frame exists.
@@ -100,22 +100,28 @@ __device__ __forceinline__ void mel_sweep(const FwdParams& p, const float* __res
   using namespace w400;
   const float* __restrict__ pr = P + (lane >> 2) * PW + (lane & 3) + 4 * klo;
   float acc_cur = 0.0f, acc_next = 0.0f;
+  const float pinf = opaque_vgpr(INFINITY), ninf = opaque_vgpr(-INFINITY);
+  unsigned voff = 4u * (unsigned)lane;
+  const unsigned f4 = 4u * (unsigned)p.F;  // launcher guarantees n_mels * F * 4 < 2^32
   auto emit = [&]() {  // the filter in progress is complete
     float outv = acc_cur;
     if (EPI == MIA_EPI_WHISPER) {
       // (log10(max(x, 1e-10)) + 4) / 4 as one FMA on log2
-      outv = fmaf(__builtin_amdgcn_logf(max_raw(acc_cur, 1e-10f)), 0.25f * 0.30102999566f, 1.0f);
+      outv = fmaf(__builtin_amdgcn_logf(max_raw(acc_cur, 1e-10f, pinf)), 0.25f * 0.30102999566f, 1.0f);
     } else if (EPI == MIA_EPI_DB) {
       // coef * log10(max(x, amin) / ref)
-      outv = fmaf(__builtin_amdgcn_logf(max_raw(acc_cur, p.amin)), p.coef * 0.30102999566f,
+      outv = fmaf(__builtin_amdgcn_logf(max_raw(acc_cur, p.amin, pinf)), p.coef * 0.30102999566f,
                   p.db_floor_shift);
     }
     if (EPI != MIA_EPI_NONE && (FULL || valid)) {
-      vmax = max_raw(vmax, outv);
-      vmin = min_raw(vmin, outv);
+      vmax = max_raw(vmax, outv, pinf);
+      vmin = min_raw(vmin, outv, ninf);
     }
-    if ((FULL || valid) && !MIA_DBG(p, 4)) rowp[lane] = outv;
-    rowp += p.F;
+    // wave-uniform row base + a 32-bit lane offset that steps one row per emit
+    if ((FULL || valid) && !MIA_DBG(p, 4)) {
+      *reinterpret_cast<float*>(reinterpret_cast<char*>(rowp) + voff) = outv;
+    }
+    voff += f4;
     acc_cur = acc_next;
     acc_next = 0.0f;
   };
@@ -155,26 +161,22 @@ __device__ __forceinline__ void mel_sweep(const FwdParams& p, const float* __res
   }
 }
 
-// Write one tile's samples (fetched as float4) into the span buffer.
-__device__ __forceinline__ void span_store(float* __restrict__ span,
-                                           const float4 (&regs)[w400::NPRE], int tid) {
+// Four consecutive samples.  Clips need not start on a 16-byte boundary (odd clip
+// lengths): the type only promises float alignment.
+struct __attribute__((packed, aligned(4))) float4_a4 {
+  float x, y, z, w;
+};
+
+// Fetch this lane's share of the 880 samples under the wave's 4 frames, four per
+// register quad.  Quads that lie wholly inside the clip are one vector load; the few
+// that touch a clip boundary go sample by sample through the padding rule.
+__device__ __forceinline__ void wave_fetch(float4 (&regs)[w400::NPRE], const float* __restrict__ yb,
+                                           long long T, long long s_wave, int pad_mode, int lane) {
   using namespace w400;
 #pragma unroll
   for (int i = 0; i < NPRE; ++i) {
-    const int q = tid + i * WG;
-    if (q < SPAN4) *reinterpret_cast<float4*>(span + RS * (q / 40) + 4 * (q % 40)) = regs[i];
-  }
-}
-// Fetch this thread's share of a tile's 10480 samples, four per register quad.
-// Quads that lie wholly inside the clip are one vector load; the few that touch
-// a clip boundary go sample by sample through the padding rule.
-__device__ __forceinline__ void span_fetch(float4 (&regs)[w400::NPRE], const float* __restrict__ yb,
-                                           long long T, long long s_begin, int pad_mode, int tid) {
-  using namespace w400;
-#pragma unroll
-  for (int i = 0; i < NPRE; ++i) {
-    const int q = tid + i * WG;
-    const long long s0 = s_begin + 4 * (q < SPAN4 ? q : SPAN4 - 1);
+    const int q = lane + 64 * i;
+    const long long s0 = s_wave + 4 * (q < WQ ? q : WQ - 1);
     if (s0 >= 0 && s0 + 4 <= T) {
       const float4_a4 v = *reinterpret_cast<const float4_a4*>(yb + s0);
       regs[i] = {v.x, v.y, v.z, v.w};
@@ -182,6 +184,16 @@ __device__ __forceinline__ void span_fetch(float4 (&regs)[w400::NPRE], const flo
       regs[i] = {fetch_sample(yb, T, s0, pad_mode), fetch_sample(yb, T, s0 + 1, pad_mode),
                  fetch_sample(yb, T, s0 + 2, pad_mode), fetch_sample(yb, T, s0 + 3, pad_mode)};
     }
+  }
+}
+// Write them to the wave's staging area: sample s at RS * (s / 160) + s % 160.
+__device__ __forceinline__ void wave_stage(float* __restrict__ stage,
+                                           const float4 (&regs)[w400::NPRE], int lane) {
+  using namespace w400;
+#pragma unroll
+  for (int i = 0; i < NPRE; ++i) {
+    const int q = lane + 64 * i;
+    if (q < WQ) *reinterpret_cast<float4*>(stage + RS * (q / 40) + 4 * (q % 40)) = regs[i];
   }
 }
 
@@ -196,8 +208,6 @@ __global__ __launch_bounds__(w400::WG, 4) void logmel400_kernel(
   // the compiler must assume they alias the output and falls back to vector loads.
   using namespace w400;
   __shared__ __attribute__((aligned(16))) float lds[LDS_DWORDS];
-  float* __restrict__ span = lds;
-  float* __restrict__ P = lds + SPAN_DWORDS;  // the 16 per-wave regions
 
   const int tid0 = threadIdx.x;
   const int wv = __builtin_amdgcn_readfirstlane(tid0 >> 6);  // wave: frames 4 wv .. 4 wv + 3
@@ -218,40 +228,42 @@ __global__ __launch_bounds__(w400::WG, 4) void logmel400_kernel(
   float wnd[25];
   float2 twd[13];
 #pragma unroll
-  for (int r = 0; r < 25; ++r) {
-    wnd[r] = g_win[32 * role0 + r];
-    asm volatile("" : "+v"(wnd[r]));  // opaque: never re-fetched inside the loop
-  }
+  for (int r = 0; r < 25; ++r) wnd[r] = g_win[32 * role0 + r];
 #pragma unroll
-  for (int k = 1; k < 13; ++k) {
-    twd[k] = g_tw[16 * role0 + k];
-    asm volatile("" : "+v"(twd[k].x), "+v"(twd[k].y));
-  }
+  for (int k = 1; k < 13; ++k) twd[k] = g_tw[16 * role0 + k];
+  // opaque from here on: never re-fetched inside the loop
+#pragma unroll
+  for (int r = 0; r < 25; ++r) asm volatile("" : "+v"(wnd[r]));
+#pragma unroll
+  for (int k = 1; k < 13; ++k) asm volatile("" : "+v"(twd[k].x), "+v"(twd[k].y));
 
   int cur_b = first / p.tiles;             // clip and tile-in-clip of the current tile,
   int cur_tile = first - cur_b * p.tiles;  // advanced incrementally
 
-  // ---- the first tile's samples ---------------------------------------------------------
-  {
-    const float* __restrict__ yb = g_y + (long long)cur_b * p.T;
-    const long long s_begin = (long long)cur_tile * (FT * HOP) - p.pad;
-    float4 regs[NPRE];
-    span_fetch(regs, yb, p.T, s_begin, p.pad_mode, tid0);
-    span_store(span, regs, tid0);
-  }
-
   // Running extremes of the clip this wave is in; they leave the wave (one atomic
   // pair) only when the clip or the run of tiles ends.
   float vmax = -INFINITY, vmin = INFINITY;
+  float* __restrict__ mine = lds + wv * PW;  // this wave's region: slot 0 | scratch | slot 1
+  // (slot + scratch is one run of LDS whichever slot a tile uses)
+
+  // ---- the first tile's samples ---------------------------------------------------------
+  {
+    const float* __restrict__ yb = g_y + (long long)cur_b * p.T;
+    const long long s_wave = (long long)cur_tile * (FT * HOP) - p.pad + 4 * wv * HOP;
+    float4 regs[NPRE];
+    wave_fetch(regs, yb, p.T, s_wave, p.pad_mode, tid0 & 63);
+    wave_stage(mine, regs, tid0 & 63);
+  }
+
   int it = 0;
   for (int idx = first; idx < last; ++idx, ++it) {
-    const long long b = cur_b;
+    const int b = cur_b;
     const int tile = cur_tile;
     if (++cur_tile == p.tiles) {
       cur_tile = 0;
       ++cur_b;
     }
-    const long long f0 = (long long)tile * FT;
+    const bool more = idx + 1 < last;
     // Re-derive the lane-dependent addresses every tile instead of keeping
     // loop-invariant VGPRs alive across the whole loop body.
     int tid = tid0;
@@ -260,89 +272,102 @@ __global__ __launch_bounds__(w400::WG, 4) void logmel400_kernel(
     const int role = lane & 15;  // pass 1: role t; pass 2: butterfly k1
     const int fi = lane >> 4;    // frame of the wave's four
     STAMP(0)
-    __syncthreads();  // this tile's samples are staged; every wave has finished the previous mel sweep
-    STAMP(1)
 
-    // ---- fetch the next tile's samples; they land during the FFT phase --------------------
+    // ---- fetch the next tile's samples; they land during the FFT --------------------------
     float4 regs[NPRE];
-    const bool more = idx + 1 < last;
-    const float* __restrict__ ynb = g_y + (long long)cur_b * p.T;  // cur_* already advanced
-    const long long sn = (long long)cur_tile * (FT * HOP) - p.pad;
 #pragma unroll
     for (int i = 0; i < NPRE; ++i) regs[i] = {0.0f, 0.0f, 0.0f, 0.0f};  // defined on every path
-    if (more) span_fetch(regs, ynb, p.T, sn, p.pad_mode, tid);
-
-    float* __restrict__ mine = P + wv * PW;  // this wave's exchange / power region
-    // ---- pass 1: real radix-25 over x[t + 16 r] of frame 4 wv + fi, then the step twiddle --
-    {
-      float2 y[13];
-      const float* __restrict__ sp = span + RS * (4 * wv + fi) + role;
-      float x[25];
-#pragma unroll
-      for (int r = 0; r < 25; ++r) x[r] = sp[16 * r + (RS - HOP) * (r / 10)] * wnd[r];
-      rdft25(x, y);
-#pragma unroll
-      for (int k = 1; k < 13; ++k) y[k] = cmul(y[k], twd[k]);
-      float2* __restrict__ exw = reinterpret_cast<float2*>(mine + EXF * fi + 26 * role);
-#pragma unroll
-      for (int c = 0; c < 13; ++c) exw[c] = y[c];
+    if (more) {
+      const float* __restrict__ ynb = g_y + (long long)cur_b * p.T;  // cur_* already advanced
+      const long long sn = (long long)cur_tile * (FT * HOP) - p.pad + 4 * wv * HOP;
+      wave_fetch(regs, ynb, p.T, sn, p.pad_mode, lane);
     }
-    STAMP(2)
-    // The exchange is private to the wave: LDS operations of one wave complete in
-    // order, so only the compiler has to be kept from moving them.
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    STAMP(1)
 
-    // ---- pass 2: radix-16 over the roles; v[k2] = X[k1 + 25 k2] (lanes k1 = 13..15 idle along) --
-    float pw[16];
+    float* __restrict__ slot = mine + (it & 1) * (SL + SC);
     {
-      float2 v[16];
-      const int k1r = role < 13 ? role : 12;
-      const float2* __restrict__ exr = reinterpret_cast<const float2*>(mine + EXF * fi + 2 * k1r);
+      const float* __restrict__ stage = mine + (it & 1) * SL;
+      // exchange area of this lane's frame: frames 0, 1 in the slot, 2, 3 in the scratch
+      float* __restrict__ exf = (fi < 2 ? slot : mine + SL - 2 * EXF) + EXF * fi;
+      // The staging and the exchange are private to the wave: LDS operations of one
+      // wave complete in order, so only the compiler has to be kept from moving them.
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      // ---- pass 1: real radix-25 over x[t + 16 r] of frame 4 wv + fi, then the step twiddle --
+      {
+        float2 y[13];
+        float x[25];
+        const float* __restrict__ sp = stage + RS * fi + role;
 #pragma unroll
-      for (int q = 0; q < 16; ++q) v[q] = exr[13 * q];
-      Dft<16>::run(v);
+        for (int r = 0; r < 25; ++r) x[r] = sp[16 * r + (RS - HOP) * (r / 10)] * wnd[r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        rdft25(x, y);
 #pragma unroll
-      for (int k2 = 0; k2 < 16; ++k2) pw[k2] = fmaf(v[k2].x, v[k2].x, v[k2].y * v[k2].y);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    STAMP(3)
+        for (int k = 1; k < 13; ++k) y[k] = cmul(y[k], twd[k]);
+        float2* __restrict__ exw = reinterpret_cast<float2*>(exf + 26 * role);
+#pragma unroll
+        for (int c = 0; c < 13; ++c) exw[c] = y[c];
+      }
+      STAMP(2)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 
-    // ---- power columns of the wave's 4 frames: mine[4 * bin + fi] ---------------------------
-    if (lane < 32) mine[4 * BINS + lane] = 0.0f;  // bins 201..208: read (zero weight) by a padded chunk
-    if (role < 13) {
-      float* __restrict__ pa = mine + 4 * role + fi;          // bins k1 + 25 k2, k2 = 0..7
-      float* __restrict__ pb = mine + 4 * (200 - role) + fi;  // bins 400 - (k1 + 25 k2), k2 = 8..15
+      // ---- pass 2: radix-16 over the roles; v[k2] = X[k1 + 25 k2] (lanes k1 = 13..15 idle along) --
+      float pw[16];
+      {
+        float2 v[16];
+        const int k1r = role < 13 ? role : 12;
+        const float2* __restrict__ exr = reinterpret_cast<const float2*>(exf + 2 * k1r);
 #pragma unroll
-      for (int k2 = 0; k2 < 8; ++k2) pa[4 * 25 * k2] = pw[k2];
-      pb[0] = pw[8];
-      if (role != 0) {  // butterfly 0 repeats bins 175, 150, ... it already wrote
+        for (int q = 0; q < 16; ++q) v[q] = exr[13 * q];
+        Dft<16>::run(v);
 #pragma unroll
-        for (int k2 = 9; k2 < 16; ++k2) pb[-4 * 25 * (k2 - 8)] = pw[k2];
+        for (int k2 = 0; k2 < 16; ++k2) pw[k2] = fmaf(v[k2].x, v[k2].x, v[k2].y * v[k2].y);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      STAMP(3)
+
+      // ---- power columns of the wave's 4 frames: slot[4 * bin + fi] ---------------------------
+      if (lane < 32) slot[4 * BINS + lane] = 0.0f;  // bins 201..208: read (zero weight) by a padded chunk
+      if (role < 13) {
+        float* __restrict__ pa = slot + 4 * role + fi;          // bins k1 + 25 k2, k2 = 0..7
+        float* __restrict__ pb = slot + 4 * (200 - role) + fi;  // bins 400 - (k1 + 25 k2), k2 = 8..15
+#pragma unroll
+        for (int k2 = 0; k2 < 8; ++k2) pa[4 * 25 * k2] = pw[k2];
+        pb[0] = pw[8];
+        if (role != 0) {  // butterfly 0 repeats bins 175, 150, ... it already wrote
+#pragma unroll
+          for (int k2 = 9; k2 < 16; ++k2) pb[-4 * 25 * (k2 - 8)] = pw[k2];
+        }
       }
     }
+    // The fetched samples are waited for HERE, a whole FFT after their loads and after
+    // the previous sweep's stores; behind the sweep the wait would include the
+    // acknowledgements of the stores just issued (the counter retires in order).
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
     STAMP(4)
-    __syncthreads();  // the power tile is complete; nobody reads the span buffer any more
+    // The power of this tile is complete, and every wave is done with the previous sweep.
+    __syncthreads();
     STAMP(5)
-
-    // ---- stage the next tile --------------------------------------------------------------
-    if (more) span_store(span, regs, tid);
-    STAMP(6)
 
     // ---- mel sweep + log epilogue (lane = frame) --------------------------------------------
     if (!MIA_DBG(p, 1)) {
+      const long long f0 = (long long)tile * FT;
       const bool valid = f0 + lane < p.F;
+      const float* __restrict__ P = lds + (it & 1) * (SL + SC);
       // wave-uniform row pointer + lane offset: the row step is scalar arithmetic
-      float* __restrict__ rowp = g_out + ((b * p.n_mels + m0) * p.F + f0);
+      float* __restrict__ rowp = g_out + (((long long)b * p.n_mels + m0) * p.F + f0);
       if (f0 + FT <= p.F) {
         mel_sweep<EPI, true>(p, P, prog, klo, nchunks, npre, rowp, lane, true, vmax, vmin);
       } else {
         mel_sweep<EPI, false>(p, P, prog, klo, nchunks, npre, rowp, lane, valid, vmax, vmin);
       }
-
       if (EPI != MIA_EPI_NONE && g_maxkey != nullptr && (cur_tile == 0 || !more)) {
         float rmax = vmax, rmin = vmin;
 #pragma unroll
@@ -360,6 +385,11 @@ __global__ __launch_bounds__(w400::WG, 4) void logmel400_kernel(
         vmin = INFINITY;
       }
     }
+    STAMP(6)
+
+    // ---- the next tile's samples pass through its (now unused) exchange area to reach
+    // the lanes that transform them --------------------------------------------------------
+    if (more) wave_stage(mine + ((it + 1) & 1) * SL, regs, lane);
     STAMP(7)
   }
 }
@@ -375,11 +405,11 @@ int launch_logmel400(const FwdParams& p0, const W400Tables& tb, hipStream_t s) {
   p.tiles = (int)((p.F + w400::FT - 1) / w400::FT);
   const long long total = p.B * p.tiles;
   if (total <= 0) return MIA_OK;
-  if (total >= (1LL << 31)) {
-    set_error("batch too large for one launch: %lld tiles (split the batch)", total);
+  if (total >= (1LL << 31) || p.n_mels * p.F >= (1LL << 30)) {
+    set_error("batch too large for one launch: %lld tiles of %lld frames (split the batch)", total, p.F);
     return MIA_ERR_UNSUPPORTED;
   }
-  // Persistent grid: one workgroup per CU (153 KB of LDS), each walking a
+  // Persistent grid: one workgroup per CU (158 KB of LDS), each walking a
   // contiguous run of tiles (consecutive tiles of a clip share cache lines of the
   // output rows, so one workgroup - one L2 - writes both halves of each line).
   int dev = 0, cus = 256;
