@@ -602,6 +602,8 @@ static int mel_forward(const mia_plan* plan, const float* y, int64_t B, int64_t 
   p.row_len = plan->d_row_len;
   p.row_off = plan->d_row_off;
   p.wts = plan->d_wts;
+  p.nnz = plan->nnz;
+  p.lds_tables = 0;
   p.power = plan->power;
   p.power_mode = plan->power == 2.0f ? 0 : (plan->power == 1.0f ? 1 : 2);
   p.mout = out;
@@ -678,6 +680,8 @@ int mia_mfcc(const mia_plan* plan, const float* y, int64_t B, int64_t T, float t
   p.row_len = plan->d_row_len;
   p.row_off = plan->d_row_off;
   p.wts = plan->d_wts;
+  p.nnz = plan->nnz;
+  p.lds_tables = 0;
   p.power = plan->power;
   p.power_mode = plan->power == 2.0f ? 0 : (plan->power == 1.0f ? 1 : 2);
   p.mout = sdb;

@@ -106,6 +106,8 @@ struct FwdParams {
   const int* row_len;
   const int* row_off;
   const float* wts;
+  int nnz;         // entries of wts
+  int lds_tables;  // the launcher found room for row_lo/row_len/row_off/wts in LDS
   int power_mode;  // 0: |X|^2, 1: |X|, 2: |X|^p
   float power;
   float* mout;

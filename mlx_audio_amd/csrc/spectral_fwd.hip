@@ -111,13 +111,95 @@ __global__ __launch_bounds__(WG) void fwd_kernel(FwdParams p) {
   bool active;
   C::map(tid, g, t, active);
   float2* buf = bufs + (active ? g : 0) * C::LBUF;
-  const long long b = blockIdx.x / p.tiles;
-  const int tile = blockIdx.x % p.tiles;
-  const long long f0 = (long long)tile * FT;
-  const float* __restrict__ yb = p.y + b * p.T;
   const float2* __restrict__ tw = p.tw;
   const float2* __restrict__ win2 = reinterpret_cast<const float2*>(p.win);
   const bool t0 = (t == 0);
+
+  // Persistent workgroup: a contiguous run of tiles.  Everything a thread needs from
+  // the window and twiddle tables depends on its position t in the group only, so it
+  // is fetched once, here, and stays in registers for the whole run (a wave-wide table
+  // load costs the texture addresser as much as a 16-byte-per-lane data load, and the
+  // passes below would issue one per element).
+  constexpr int R0 = C::R0, S0 = M / R0, NB0 = S0 / T;
+  constexpr int R1 = C::R1, S1 = M / R1, NB1 = (C::NPASS == 3) ? S1 / T : 1;
+  constexpr int RL = C::RL, NSL = C::NSL;
+  float2 wn[NB0][R0];        // window taps of the thread's sample pairs
+  float2 tw1[NB1][R1];       // middle-pass twiddles (3-pass plans)
+  float2 twa[RL], twb[RL];   // last-pass twiddles of butterflies t and NSL - t
+  float2 tws[RL];            // split-step twiddles
+  {
+    const int tt = active ? t : 0;
+#pragma unroll
+    for (int bb = 0; bb < NB0; ++bb) {
+#pragma unroll
+      for (int r = 0; r < R0; ++r) wn[bb][r] = win2[tt + bb * T + r * S0];
+    }
+    if constexpr (C::NPASS == 3) {
+      constexpr int NS = C::R0, TWS = 2 * (M / (NS * R1));  // step in the n_fft-entry table
+#pragma unroll
+      for (int bb = 0; bb < NB1; ++bb) {
+        const int jm = (tt + bb * T) % NS;
+#pragma unroll
+        for (int r = 1; r < R1; ++r) tw1[bb][r] = tw[jm * r * TWS];
+      }
+    }
+    const int jA = tt, jB = tt == 0 ? NSL / 2 : NSL - tt;
+#pragma unroll
+    for (int r = 1; r < RL; ++r) {
+      twa[r] = tw[2 * jA * r];
+      twb[r] = tw[2 * jB * r];
+    }
+    static_for<0, RL>([&](auto rc) {
+      constexpr int r = decltype(rc)::value;
+      constexpr T0Pair ps = t0_pair<RL>(r);
+      tws[r] = tw[tt == 0 ? ps.k_half * (NSL / 2) : tt + NSL * r];
+    });
+    // opaque from here on: never re-fetched inside the loop
+#pragma unroll
+    for (int bb = 0; bb < NB0; ++bb) {
+#pragma unroll
+      for (int r = 0; r < R0; ++r) asm volatile("" : "+v"(wn[bb][r].x), "+v"(wn[bb][r].y));
+    }
+    if constexpr (C::NPASS == 3) {
+#pragma unroll
+      for (int bb = 0; bb < NB1; ++bb) {
+#pragma unroll
+        for (int r = 1; r < R1; ++r) asm volatile("" : "+v"(tw1[bb][r].x), "+v"(tw1[bb][r].y));
+      }
+    }
+#pragma unroll
+    for (int r = 1; r < RL; ++r) {
+      asm volatile("" : "+v"(twa[r].x), "+v"(twa[r].y), "+v"(twb[r].x), "+v"(twb[r].y));
+    }
+#pragma unroll
+    for (int r = 0; r < RL; ++r) asm volatile("" : "+v"(tws[r].x), "+v"(tws[r].y));
+  }
+
+  // Band tables of the mel stage: in LDS behind the power tile when the launcher found
+  // room (one copy per persistent workgroup), else read from global memory.
+  float* const lds_wts = P + FT * PS;
+  int* const lds_rows = reinterpret_cast<int*>(lds_wts + (MODE == 1 ? p.nnz : 0));
+  if constexpr (MODE == 1) {
+    if (p.lds_tables) {
+      for (int i = tid; i < p.nnz; i += WG) lds_wts[i] = p.wts[i];
+      for (int i = tid; i < p.n_mels; i += WG) {
+        lds_rows[i] = p.row_lo[i];
+        lds_rows[p.n_mels + i] = p.row_len[i];
+        lds_rows[2 * p.n_mels + i] = p.row_off[i];
+      }
+      __syncthreads();
+    }
+  }
+
+  const long long total = p.B * p.tiles;
+  const long long first = (long long)blockIdx.x * p.tiles_per_wg;
+  const long long last = first + p.tiles_per_wg < total ? first + p.tiles_per_wg : total;
+
+  for (long long idx = first; idx < last; ++idx) {
+  const long long b = idx / p.tiles;
+  const int tile = (int)(idx - b * p.tiles);
+  const long long f0 = (long long)tile * FT;
+  const float* __restrict__ yb = p.y + b * p.T;
 
   if (active) {
     for (int it = 0; it < ITERS; ++it) {
@@ -131,7 +213,7 @@ __global__ __launch_bounds__(WG) void fwd_kernel(FwdParams p) {
 
       // ---- pass 0: windowed samples -> radix R0 -> LDS ----------------------
       {
-        constexpr int R = C::R0, S = M / R, NB = S / T;
+        constexpr int R = R0, S = S0, NB = NB0;
         float2 v[NB][R];
 #pragma unroll
         for (int bb = 0; bb < NB; ++bb) {
@@ -153,8 +235,7 @@ __global__ __launch_bounds__(WG) void fwd_kernel(FwdParams p) {
             } else {
               x = {0.0f, 0.0f};
             }
-            const float2 w = win2[n];
-            v[bb][r] = {x.x * w.x, x.y * w.y};
+            v[bb][r] = {x.x * wn[bb][r].x, x.y * wn[bb][r].y};
           }
         }
 #pragma unroll
@@ -173,17 +254,15 @@ __global__ __launch_bounds__(WG) void fwd_kernel(FwdParams p) {
 
       // ---- middle pass (3-pass plans) ---------------------------------------
       if constexpr (C::NPASS == 3) {
-        constexpr int R = C::R1, S = M / R, NB = S / T, NS = C::R0;
-        constexpr int TWS = 2 * (M / (NS * R));  // step in the n_fft-entry table
+        constexpr int R = R1, S = S1, NB = NB1, NS = C::R0;
         float2 v[NB][R];
 #pragma unroll
         for (int bb = 0; bb < NB; ++bb) {
           const int j = t + bb * T;
-          const int jm = j % NS;
 #pragma unroll
           for (int r = 0; r < R; ++r) {
             float2 x = buf[C::template pos_strided<S>(j, r)];
-            if (r > 0) x = cmul(x, tw[jm * r * TWS]);
+            if (r > 0) x = cmul(x, tw1[bb][r]);
             v[bb][r] = x;
           }
         }
@@ -201,7 +280,6 @@ __global__ __launch_bounds__(WG) void fwd_kernel(FwdParams p) {
       }
 
       // ---- last pass: butterflies t and NSL - t ------------------------------
-      constexpr int RL = C::RL, NSL = C::NSL;
       float2 A[RL], Bv[RL];
       {
         const int jA = t;
@@ -211,8 +289,8 @@ __global__ __launch_bounds__(WG) void fwd_kernel(FwdParams p) {
           float2 xa = buf[C::template pos_strided<NSL>(jA, r)];
           float2 xb = buf[C::template pos_strided<NSL>(jB, r)];
           if (r > 0) {
-            xa = cmul(xa, tw[2 * jA * r]);
-            xb = cmul(xb, tw[2 * jB * r]);
+            xa = cmul(xa, twa[r]);
+            xb = cmul(xb, twb[r]);
           }
           A[r] = xa;
           Bv[r] = xb;
@@ -245,7 +323,7 @@ __global__ __launch_bounds__(WG) void fwd_kernel(FwdParams p) {
         const float2 U = t0 ? U0 : A[r];
         const float2 V = t0 ? V0 : Bv[RL - 1 - r];
         const int k = t0 ? ps.k_half * (NSL / 2) : t + NSL * r;
-        const float2 w = tw[k];
+        const float2 w = tws[r];
         // E = U + conj(V);  O = -i (U - conj(V));  X[k] = (E + w O)/2,
         // X[M-k] = conj(E - w O)/2.
         const float2 E = {U.x + V.x, U.y - V.y};
@@ -266,28 +344,37 @@ __global__ __launch_bounds__(WG) void fwd_kernel(FwdParams p) {
     const long long frem = p.F - f0;
     const int fcount = frem < FT ? (int)frem : FT;
     float vmax = -INFINITY, vmin = INFINITY;
-    for (int idx = tid; idx < p.n_mels * FT; idx += WG) {
-      const int m = idx / FT;
-      const int fl = idx - m * FT;
-      if (fl >= fcount) continue;
-      const int lo = p.row_lo[m], len = p.row_len[m];
-      const float* __restrict__ w = p.wts + p.row_off[m];
-      const float* __restrict__ pr = P + fl * PS + lo;
-      float acc = 0.0f;
-      for (int j = 0; j < len; ++j) acc = fmaf(w[j], pr[j], acc);
-      float outv = acc;
-      if (p.epi == MIA_EPI_WHISPER) {
-        // values at or below the 1e-10 floor give exactly log10(1e-10) = -10
-        const float yv = acc <= 1e-10f ? -10.0f : __log10f(acc);
-        vmax = fmaxf(vmax, yv);
-        outv = (yv + 4.0f) * 0.25f;
-        vmin = fminf(vmin, outv);
-      } else if (p.epi == MIA_EPI_DB) {
-        outv = acc <= p.amin ? p.db_floor : p.coef * __log10f(acc * p.inv_ref);
-        vmax = fmaxf(vmax, outv);
-        vmin = fminf(vmin, outv);
+    // one instantiation per table location, so that each knows its address space
+    auto project = [&](const int* row_lo, const int* row_len, const int* row_off, const float* wts) {
+      for (int idx2 = tid; idx2 < p.n_mels * FT; idx2 += WG) {
+        const int m = idx2 / FT;
+        const int fl = idx2 - m * FT;
+        if (fl >= fcount) continue;
+        const int lo = row_lo[m], len = row_len[m];
+        const float* w = wts + row_off[m];
+        const float* __restrict__ pr = P + fl * PS + lo;
+        float acc = 0.0f;
+#pragma unroll 4
+        for (int j = 0; j < len; ++j) acc = fmaf(w[j], pr[j], acc);
+        float outv = acc;
+        if (p.epi == MIA_EPI_WHISPER) {
+          // values at or below the 1e-10 floor give exactly log10(1e-10) = -10
+          const float yv = acc <= 1e-10f ? -10.0f : __log10f(acc);
+          vmax = fmaxf(vmax, yv);
+          outv = (yv + 4.0f) * 0.25f;
+          vmin = fminf(vmin, outv);
+        } else if (p.epi == MIA_EPI_DB) {
+          outv = acc <= p.amin ? p.db_floor : p.coef * __log10f(acc * p.inv_ref);
+          vmax = fmaxf(vmax, outv);
+          vmin = fminf(vmin, outv);
+        }
+        p.mout[(b * p.n_mels + m) * p.F + f0 + fl] = outv;
       }
-      p.mout[(b * p.n_mels + m) * p.F + f0 + fl] = outv;
+    };
+    if (p.lds_tables) {
+      project(lds_rows, lds_rows + p.n_mels, lds_rows + 2 * p.n_mels, lds_wts);
+    } else {
+      project(p.row_lo, p.row_len, p.row_off, p.wts);
     }
     if (p.epi != MIA_EPI_NONE && p.clip_max_key != nullptr) {
 #pragma unroll
@@ -311,7 +398,9 @@ __global__ __launch_bounds__(WG) void fwd_kernel(FwdParams p) {
         atomicMin(p.clip_min_key + b, float_to_key(vmin));
       }
     }
+    __syncthreads();  // the next tile overwrites the power tile and the reduction slots
   }
+  }  // tiles of this workgroup
 }
 
 // ---------------------------------------------------------------------------
@@ -333,22 +422,50 @@ static int launch_cfg(const FwdParams& p0, hipStream_t s) {
   constexpr int PS = (C::M + 1) | 1;
   FwdParams p = p0;
   p.tiles = (int)((p.F + FT - 1) / FT);
-  const size_t lds = sizeof(float2) * G * C::LBUF + (MODE == 1 ? sizeof(float) * FT * PS : 0);
+  size_t lds = sizeof(float2) * G * C::LBUF + (MODE == 1 ? sizeof(float) * FT * PS : 0);
+  if (MODE == 1) {
+    // band tables ride along in LDS when two workgroups still fit a CU
+    const size_t tables = sizeof(float) * (size_t)p.nnz + 3 * sizeof(int) * (size_t)p.n_mels;
+    if (lds + tables <= 80 * 1024) {
+      lds += tables;
+      p.lds_tables = 1;
+    }
+  }
   static_assert(sizeof(float2) * G * C::LBUF + (MODE == 1 ? sizeof(float) * FT * PS : 0) <=
                     160 * 1024,
                 "LDS budget");
-  const long long blocks = p.B * p.tiles;
-  if (blocks <= 0) return MIA_OK;
-  if (blocks > 0x7fffffffLL) {
-    set_error("grid too large: %lld workgroups", blocks);
-    return MIA_ERR_INVALID;
-  }
+  const long long total = p.B * p.tiles;
+  if (total <= 0) return MIA_OK;
   auto kern = fwd_kernel<C, MODE, WG, ITERS>;
   if (lds > 64 * 1024) {
     MIA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(WG), lds, s, p);
+  // Persistent grid: as many workgroups as the device holds at once, each walking a
+  // contiguous run of tiles.
+  static int resident[16] = {0};  // workgroups per device for this instantiation
+  int dev = 0;
+  MIA_CHECK_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 16) dev = 0;
+  if (resident[dev] == 0) {
+    int cus = 256, per_cu = 1;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), WG,
+                                                     lds) != hipSuccess || per_cu < 1) {
+      per_cu = 1;
+    }
+    resident[dev] = cus * per_cu;
+  }
+  long long grid = resident[dev];
+  if (grid > total) grid = total;
+  const long long per_wg = (total + grid - 1) / grid;
+  if (per_wg > 0x7fffffffLL) {
+    set_error("batch too large for one launch: %lld tiles (split the batch)", total);
+    return MIA_ERR_UNSUPPORTED;
+  }
+  p.tiles_per_wg = (int)per_wg;
+  grid = (total + per_wg - 1) / per_wg;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WG), lds, s, p);
   MIA_CHECK_HIP(hipGetLastError());
   return MIA_OK;
 }
