@@ -97,7 +97,7 @@ constexpr T0Pair t0_pair(int s) {
 }
 
 template <class C, int MODE, int WG, int ITERS>
-__global__ __launch_bounds__(WG) void fwd_kernel(FwdParams p) {
+__global__ __launch_bounds__(WG, 2) void fwd_kernel(FwdParams p) {
   constexpr int M = C::M, T = C::T, N = C::N;
   constexpr int G = C::template groups<WG>();
   constexpr int FT = G * ITERS;
@@ -195,6 +195,33 @@ __global__ __launch_bounds__(WG) void fwd_kernel(FwdParams p) {
   const long long first = (long long)blockIdx.x * p.tiles_per_wg;
   const long long last = first + p.tiles_per_wg < total ? first + p.tiles_per_wg : total;
 
+  // Raw sample pairs of the frame this group transforms next, fetched one frame ahead
+  // (behind the last pass's LDS reads of the current frame) when that frame lies wholly
+  // inside its signal and is 8-byte aligned; other frames are loaded when they are used.
+  float2 xin[NB0][R0];
+  bool pre_ok = false;
+#pragma unroll
+  for (int bb = 0; bb < NB0; ++bb) {
+#pragma unroll
+    for (int r = 0; r < R0; ++r) xin[bb][r] = {0.0f, 0.0f};
+  }
+  auto prefetch = [&](long long idx_n, int it_n) {
+    const long long bn = idx_n / p.tiles;
+    const long long fn = (idx_n - bn * p.tiles) * FT + it_n * G + g;
+    const float* __restrict__ ybn = p.y + bn * p.T;
+    const long long s0 = fn * p.hop - p.pad;
+    pre_ok = idx_n < last && fn < p.F && s0 >= 0 && s0 + N <= p.T &&
+             ((reinterpret_cast<uintptr_t>(ybn + s0) & 7) == 0);
+    if (pre_ok) {
+      const float2* __restrict__ src = reinterpret_cast<const float2*>(ybn + s0) + t;
+#pragma unroll
+      for (int bb = 0; bb < NB0; ++bb) {
+#pragma unroll
+        for (int r = 0; r < R0; ++r) xin[bb][r] = src[bb * T + r * S0];
+      }
+    }
+  };
+
   for (long long idx = first; idx < last; ++idx) {
   const long long b = idx / p.tiles;
   const int tile = (int)(idx - b * p.tiles);
@@ -222,7 +249,9 @@ __global__ __launch_bounds__(WG) void fwd_kernel(FwdParams p) {
           for (int r = 0; r < R; ++r) {
             const int n = j + r * S;
             float2 x;
-            if (interior) {
+            if (pre_ok) {
+              x = xin[bb][r];
+            } else if (interior) {
               if (aligned8) {
                 x = *reinterpret_cast<const float2*>(yb + s0 + 2 * n);
               } else {
@@ -296,6 +325,11 @@ __global__ __launch_bounds__(WG) void fwd_kernel(FwdParams p) {
           Bv[r] = xb;
         }
         group_sync<C>();  // next iteration overwrites buf
+        if (it + 1 < ITERS) {
+          prefetch(idx, it + 1);
+        } else {
+          prefetch(idx + 1, 0);
+        }
         Dft<RL>::run(A);
         Dft<RL>::run(Bv);
       }
