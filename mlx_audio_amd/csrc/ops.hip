@@ -216,7 +216,8 @@ __global__ __launch_bounds__(256) void dct2_kernel(const float* __restrict__ x, 
   extern __shared__ float slab[];  // n_in x 64
   const long long o = blockIdx.y;
   const long long i0 = (long long)blockIdx.x * 64;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar: basis loads become s_load
   const float thr = keys ? floor_from_key(keys[o * key_stride], MIA_EPI_DB, top) : -INFINITY;
   const bool ok = i0 + lane < inner;
   for (int n = wave; n < n_in; n += 4) {
@@ -228,12 +229,27 @@ __global__ __launch_bounds__(256) void dct2_kernel(const float* __restrict__ x, 
     float acc[KB];
 #pragma unroll
     for (int q = 0; q < KB; ++q) acc[q] = 0.0f;
-    for (int n = 0; n < n_in; ++n) {
+    // 8 taps at a time: the basis values are wave-uniform, and in runs of 8 they arrive
+    // as wide scalar loads instead of one load (and one wait) per value
+    int n = 0;
+    for (; n + 8 <= n_in; n += 8) {
+      float xv[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) xv[j] = slab[(n + j) * 64 + lane];
+#pragma unroll
+      for (int q = 0; q < KB; ++q) {
+        const int k = k0 + q < n_out ? k0 + q : n_out - 1;
+        const float* __restrict__ brow = basis + (long long)k * n_in + n;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[q] = fmaf(brow[j], xv[j], acc[q]);
+      }
+    }
+    for (; n < n_in; ++n) {
       const float xv = slab[n * 64 + lane];
 #pragma unroll
       for (int q = 0; q < KB; ++q) {
         const int k = k0 + q < n_out ? k0 + q : n_out - 1;
-        acc[q] = fmaf(basis[k * n_in + n], xv, acc[q]);
+        acc[q] = fmaf(basis[(long long)k * n_in + n], xv, acc[q]);
       }
     }
     if (ok) {
