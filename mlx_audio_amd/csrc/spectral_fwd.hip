@@ -281,11 +281,20 @@ __global__ __launch_bounds__(WG, 2) void fwd_kernel(FwdParams p) {
               v[bb][r] = {xin[bb][r].x * wn[bb][r].x, xin[bb][r].y * wn[bb][r].y};
             }
           }
+        } else if (__all(pre_ok)) {
+          // the usual case, decided once for the wave's groups together
+#pragma unroll
+          for (int bb = 0; bb < NB; ++bb) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+              v[bb][r] = {xin[bb][r].x * wn[bb][r].x, xin[bb][r].y * wn[bb][r].y};
+            }
+          }
         } else {
 #pragma unroll
           for (int bb = 0; bb < NB; ++bb) {
             const int j = t + bb * T;
-  #pragma unroll
+#pragma unroll
             for (int r = 0; r < R; ++r) {
               const int n = j + r * S;
               float2 x;
