@@ -385,13 +385,15 @@ __global__ __launch_bounds__(WG, 2) void fwd_kernel(FwdParams p) {
       }
 
       // ---- split step in registers: bins k and M-k ---------------------------
-      float2* __restrict__ crow =
-          (MODE == 0 && valid) ? p.cout + (b * p.F + f) * (long long)(M + 1) : nullptr;
+      // (frames past the end exist only in plans whose groups span waves; they took part
+      // in the passes for the barriers' sake and produce nothing)
+      if (!valid) continue;
+      float2* __restrict__ crow = MODE == 0 ? p.cout + (b * p.F + f) * (long long)(M + 1) : nullptr;
       float* __restrict__ prow = P + fl * PS;
       const float half_scale = 0.5f * p.scale;
       auto emit = [&](int k, float2 X) {
         if constexpr (MODE == 0) {
-          if (valid) crow[k] = {X.x * half_scale, X.y * half_scale};
+          crow[k] = {X.x * half_scale, X.y * half_scale};
         } else {
           float pw = 0.25f * (X.x * X.x + X.y * X.y);
           if (p.power_mode == 1) pw = sqrtf(pw);
