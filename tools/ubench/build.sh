@@ -4,5 +4,5 @@
 set -e
 cd "$(dirname "$0")"
 for f in *.hip; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -Wno-unused-result -o "${f%.hip}" "$f"
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -Wno-unused-result -Wno-unused-value -o "${f%.hip}" "$f"
 done
