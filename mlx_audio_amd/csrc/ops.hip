@@ -138,22 +138,58 @@ __global__ __launch_bounds__(256) void floor_rows_kernel(float* __restrict__ x, 
   }
 }
 
-// Floor clamp of the (B, n) feature tensor.  A clip whose minimum is already
-// above its floor is skipped without touching memory (the common case: the
-// log-mel range of most inputs is narrower than the clamp window).
+// Floor clamp of the (B, n) feature tensor.  A clip whose minimum is already above
+// its floor is never touched (the common case: the log-mel range of most inputs is
+// narrower than the clamp window), so the launch is sized for the few that are: every
+// workgroup first derives the same list of clips to clamp (1024 clips per round, flags
+// gathered by all threads, compacted in clip order by one wave), then the workgroups
+// share the (clip, chunk) items of that list.
+constexpr int kFloorChunks = 64;  // pieces a clip is cut into
 __global__ __launch_bounds__(256) void floor_clips_kernel(float* __restrict__ x, long long n,
+                                                           long long B,
                                                            const int* __restrict__ max_keys,
                                                            long long key_stride,
                                                            const int* __restrict__ min_keys,
                                                            int epi, float top) {
-  const long long b = blockIdx.y;
-  const float thr = floor_from_key(max_keys[b * key_stride], epi, top);
-  if (key_to_float(min_keys[b]) >= thr) return;
-  float* __restrict__ xb = x + b * n;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-       i += (long long)gridDim.x * blockDim.x) {
-    const float v = xb[i];
-    if (v < thr) xb[i] = thr;
+  __shared__ unsigned char need[1024];
+  __shared__ short list[1024];
+  __shared__ int count;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const long long chunk_len = (n + kFloorChunks - 1) / kFloorChunks;
+  for (long long b0 = 0; b0 < B; b0 += 1024) {
+    for (int j = tid; j < 1024; j += 256) {
+      bool nd = false;
+      if (b0 + j < B) {
+        const float thr = floor_from_key(max_keys[(b0 + j) * key_stride], epi, top);
+        nd = key_to_float(min_keys[b0 + j]) < thr;
+      }
+      need[j] = nd ? 1 : 0;
+    }
+    __syncthreads();
+    if (tid < 64) {
+      int base = 0;
+      for (int g = 0; g < 16; ++g) {
+        const bool nd = need[g * 64 + lane] != 0;
+        const unsigned long long m = __ballot(nd);
+        if (nd) list[base + __popcll(m & ((1ull << lane) - 1ull))] = (short)(g * 64 + lane);
+        base += __popcll(m);
+      }
+      if (lane == 0) count = base;
+    }
+    __syncthreads();
+    const int items = count * kFloorChunks;
+    for (int item = blockIdx.x; item < items; item += gridDim.x) {
+      const long long b = b0 + list[item / kFloorChunks];
+      const long long lo = (long long)(item % kFloorChunks) * chunk_len;
+      const long long hi = lo + chunk_len < n ? lo + chunk_len : n;
+      const float thr = floor_from_key(max_keys[b * key_stride], epi, top);
+      float* __restrict__ xb = x + b * n;
+      for (long long i = lo + tid; i < hi; i += 256) {
+        const float v = xb[i];
+        if (v < thr) xb[i] = thr;
+      }
+    }
+    __syncthreads();  // the lists are rebuilt for the next 1024 clips
   }
 }
 
@@ -192,9 +228,9 @@ int launch_floor_clips(float* x, long long B, long long n, int* max_keys, const 
     hipLaunchKernelGGL(reduce_keys_kernel, dim3(1), dim3(256), 0, s, max_keys, B);
     MIA_CHECK_HIP(hipGetLastError());
   }
-  long long bx = (n + 256 * 16 - 1) / (256 * 16);
-  if (bx > 64) bx = 64;
-  hipLaunchKernelGGL(floor_clips_kernel, dim3((unsigned)bx, (unsigned)B), dim3(256), 0, s, x, n,
+  long long grid = B * kFloorChunks;  // never more workgroups than items
+  if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL(floor_clips_kernel, dim3((unsigned)grid), dim3(256), 0, s, x, n, B,
                      per_clip ? max_keys : max_keys + B, (long long)(per_clip ? 1 : 0),
                      min_keys, epi, top);
   MIA_CHECK_HIP(hipGetLastError());
