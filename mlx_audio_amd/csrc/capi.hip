@@ -622,10 +622,7 @@ static int mel_forward(const mia_plan* plan, const float* y, int64_t B, int64_t 
     max_keys = reinterpret_cast<int*>(workspace);
     min_keys = reinterpret_cast<int*>(reinterpret_cast<char*>(workspace) +
                                       align256(sizeof(int) * (size_t)(B + 1)));
-    MIA_CHECK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(max_keys), kKeyMinusInf,
-                                    (size_t)B + 1, s));
-    MIA_CHECK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(min_keys), kKeyPlusInf,
-                                    (size_t)B + 1, s));
+    if ((rc = launch_init_keys(max_keys, min_keys, B + 1, s)) != MIA_OK) return rc;
     p.clip_max_key = max_keys;
     p.clip_min_key = min_keys;
   }
@@ -694,10 +691,7 @@ int mia_mfcc(const mia_plan* plan, const float* y, int64_t B, int64_t T, float t
   int* min_keys = reinterpret_cast<int*>(reinterpret_cast<char*>(workspace) +
                                          align256(sizeof(int) * (size_t)(B + 1)));
   const bool clamp = top_db >= 0.0f;
-  MIA_CHECK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(keys), kKeyMinusInf,
-                                  (size_t)B + 1, s));
-  MIA_CHECK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(min_keys), kKeyPlusInf,
-                                  (size_t)B + 1, s));
+  if ((rc = launch_init_keys(keys, min_keys, B + 1, s)) != MIA_OK) return rc;
   p.clip_max_key = keys;
   p.clip_min_key = min_keys;
   rc = forward_mel_dispatch(plan, p, s);

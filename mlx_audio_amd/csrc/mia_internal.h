@@ -138,6 +138,7 @@ struct InvParams {
 
 int launch_forward(const mia_plan* plan, const FwdParams& p, int mode, hipStream_t s);
 int launch_inverse(const mia_plan* plan, const InvParams& p, hipStream_t s);
+int launch_init_keys(int* max_keys, int* min_keys, long long n, hipStream_t s);
 int launch_logmel400(const FwdParams& p, const W400Tables& tb, hipStream_t s);
 bool fft_size_supported(int n_fft);
 int forward_tile_frames(int n_fft, int mode);

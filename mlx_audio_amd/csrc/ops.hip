@@ -138,6 +138,24 @@ __global__ __launch_bounds__(256) void floor_rows_kernel(float* __restrict__ x, 
   }
 }
 
+// Both key arrays of a mel call in one launch (two hipMemsetD32Async cost four fill
+// dispatches per call).
+__global__ __launch_bounds__(256) void init_keys_kernel(int* __restrict__ max_keys,
+                                                         int* __restrict__ min_keys, long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    max_keys[i] = kKeyMinusInf;
+    min_keys[i] = kKeyPlusInf;
+  }
+}
+int launch_init_keys(int* max_keys, int* min_keys, long long n, hipStream_t s) {
+  if (n <= 0) return MIA_OK;
+  hipLaunchKernelGGL(init_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, max_keys,
+                     min_keys, n);
+  MIA_CHECK_HIP(hipGetLastError());
+  return MIA_OK;
+}
+
 // Floor clamp of the (B, n) feature tensor.  A clip whose minimum is already above
 // its floor is never touched (the common case: the log-mel range of most inputs is
 // narrower than the clamp window), so the launch is sized for the few that are: every
