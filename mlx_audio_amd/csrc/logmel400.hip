@@ -47,8 +47,9 @@ constexpr int SL = 840;           // power slot: 2 frames of exchange, then 4 x 
 constexpr int SC = 2 * EXF;       // scratch: the exchange of frames 2, 3
 constexpr int PW = 2 * SL + SC + 20;  // per-wave region, 4 mod 32: conflict-free mel reads
 constexpr int WSPAN = 3 * HOP + N;    // 880 samples under a wave's 4 frames
-constexpr int WQ = WSPAN / 4;         // 220 float4
-constexpr int NPRE = (WQ + 63) / 64;  // 4 float4 per lane
+constexpr int NQ4 = 3;                // per lane: 3 float4 (samples 0..767 of the 880) ...
+constexpr int NH2 = (WSPAN - NQ4 * 256) / 2;  // ... and one float2 in the first 56 lanes (768..879)
+static_assert(NH2 > 0 && NH2 <= 64, "the tail of the wave's samples fits one float2 per lane");
 constexpr int RS = 176;               // staged sample rows: 160 samples at stride 176 (16 mod 32), so
                                       // 2 frames x 16 roles of a half-wave hit 32 different banks
 static_assert(RS * (WSPAN / HOP) + WSPAN % HOP <= SL + SC, "staged samples fit slot + scratch");
@@ -77,18 +78,19 @@ __device__ unsigned long long* g_dbgbuf = nullptr;
 #define STAMP(i)
 #endif
 
-// max / min as one v_med3_f32 each (a NaN operand loses to a number): fmaxf / fminf
-// would put a canonicalising v_max x, x, x in front of every use.  The infinity comes
-// in as an opaque register so that the compiler cannot fold the median back into them.
-__device__ __forceinline__ float opaque_vgpr(float x) {
-  asm volatile("" : "+v"(x));
-  return x;
-}
-__device__ __forceinline__ float max_raw(float a, float b, float pinf) {
-  return __builtin_amdgcn_fmed3f(a, b, pinf);
-}
-__device__ __forceinline__ float min_raw(float a, float b, float ninf) {
-  return __builtin_amdgcn_fmed3f(a, b, ninf);
+// The floor max(x, lo) of the log epilogue, written so that a NaN stays a NaN (as in the
+// reference's maximum): one compare + one select.
+__device__ __forceinline__ float floor_keep_nan(float x, float lo) { return x < lo ? lo : x; }
+
+// Log epilogue of a floored power value m.
+template <int EPI>
+__device__ __forceinline__ float log_epilogue(const FwdParams& p, float m) {
+  if (EPI == MIA_EPI_WHISPER) {
+    // (log10(m) + 4) / 4 as one FMA on log2
+    return fmaf(__builtin_amdgcn_logf(m), 0.25f * 0.30102999566f, 1.0f);
+  }
+  // coef * log10(m / ref)
+  return fmaf(__builtin_amdgcn_logf(m), p.coef * 0.30102999566f, p.db_floor_shift);
 }
 
 // Mel sweep of one wave over the power tile.  FULL: every lane's frame exists.
@@ -96,26 +98,26 @@ template <int EPI, bool FULL>
 __device__ __forceinline__ void mel_sweep(const FwdParams& p, const float* __restrict__ P,
                                           const float4* __restrict__ prog, int klo, int nchunks,
                                           int npre, float* __restrict__ rowp, int lane, bool valid,
-                                          float& vmax, float& vmin) {
+                                          unsigned& mhi, unsigned& mlo) {
   using namespace w400;
   const float* __restrict__ pr = P + (lane >> 2) * PW + (lane & 3) + 4 * klo;
   float acc_cur = 0.0f, acc_next = 0.0f;
-  const float pinf = opaque_vgpr(INFINITY), ninf = opaque_vgpr(-INFINITY);
+  float ninf = -INFINITY;
+  asm volatile("" : "+v"(ninf));  // opaque, or the median below folds back into a canonicalising min
   unsigned voff = 4u * (unsigned)lane;
   const unsigned f4 = 4u * (unsigned)p.F;  // launcher guarantees n_mels * F * 4 < 2^32
   auto emit = [&]() {  // the filter in progress is complete
     float outv = acc_cur;
-    if (EPI == MIA_EPI_WHISPER) {
-      // (log10(max(x, 1e-10)) + 4) / 4 as one FMA on log2
-      outv = fmaf(__builtin_amdgcn_logf(max_raw(acc_cur, 1e-10f, pinf)), 0.25f * 0.30102999566f, 1.0f);
-    } else if (EPI == MIA_EPI_DB) {
-      // coef * log10(max(x, amin) / ref)
-      outv = fmaf(__builtin_amdgcn_logf(max_raw(acc_cur, p.amin, pinf)), p.coef * 0.30102999566f,
-                  p.db_floor_shift);
-    }
-    if (EPI != MIA_EPI_NONE && (FULL || valid)) {
-      vmax = max_raw(vmax, outv, pinf);
-      vmin = min_raw(vmin, outv, ninf);
+    if (EPI != MIA_EPI_NONE) {
+      // The clip's extremes are tracked on the floored power itself: it is positive, so its
+      // bit pattern orders like its value, the log is monotone, and a NaN (either sign) is
+      // the largest pattern of all - it wins the maximum, as it does in the reference.
+      const float m = floor_keep_nan(acc_cur, EPI == MIA_EPI_WHISPER ? 1e-10f : p.amin);
+      outv = log_epilogue<EPI>(p, m);
+      if (FULL || valid) {
+        mhi = max(mhi, __builtin_bit_cast(unsigned, m));
+        mlo = __builtin_bit_cast(unsigned, __builtin_amdgcn_fmed3f(__builtin_bit_cast(float, mlo), m, ninf));
+      }
     }
     // wave-uniform row base + a 32-bit lane offset that steps one row per emit
     if ((FULL || valid) && !MIA_DBG(p, 4)) {
@@ -167,33 +169,49 @@ struct __attribute__((packed, aligned(4))) float4_a4 {
   float x, y, z, w;
 };
 
-// Fetch this lane's share of the 880 samples under the wave's 4 frames, four per
-// register quad.  Quads that lie wholly inside the clip are one vector load; the few
-// that touch a clip boundary go sample by sample through the padding rule.
-__device__ __forceinline__ void wave_fetch(float4 (&regs)[w400::NPRE], const float* __restrict__ yb,
-                                           long long T, long long s_wave, int pad_mode, int lane) {
+// This lane's share of the 880 samples under the wave's 4 frames: 14 registers.
+struct __attribute__((packed, aligned(4))) float2_a4 {
+  float x, y;
+};
+struct Staged {
+  float4 q[w400::NQ4];
+  float2 h;
+};
+// Fetch it.  Runs that lie wholly inside the clip are one vector load; the few that touch
+// a clip boundary go sample by sample through the padding rule.
+__device__ __forceinline__ void wave_fetch(Staged& r, const float* __restrict__ yb, long long T,
+                                           long long s_wave, int pad_mode, int lane) {
   using namespace w400;
 #pragma unroll
-  for (int i = 0; i < NPRE; ++i) {
-    const int q = lane + 64 * i;
-    const long long s0 = s_wave + 4 * (q < WQ ? q : WQ - 1);
+  for (int i = 0; i < NQ4; ++i) {
+    const long long s0 = s_wave + 4 * (lane + 64 * i);
     if (s0 >= 0 && s0 + 4 <= T) {
       const float4_a4 v = *reinterpret_cast<const float4_a4*>(yb + s0);
-      regs[i] = {v.x, v.y, v.z, v.w};
+      r.q[i] = {v.x, v.y, v.z, v.w};
     } else {
-      regs[i] = {fetch_sample(yb, T, s0, pad_mode), fetch_sample(yb, T, s0 + 1, pad_mode),
-                 fetch_sample(yb, T, s0 + 2, pad_mode), fetch_sample(yb, T, s0 + 3, pad_mode)};
+      r.q[i] = {fetch_sample(yb, T, s0, pad_mode), fetch_sample(yb, T, s0 + 1, pad_mode),
+                fetch_sample(yb, T, s0 + 2, pad_mode), fetch_sample(yb, T, s0 + 3, pad_mode)};
     }
   }
+  const long long s0 = s_wave + NQ4 * 256 + 2 * (lane < NH2 ? lane : NH2 - 1);
+  if (s0 >= 0 && s0 + 2 <= T) {
+    const float2_a4 v = *reinterpret_cast<const float2_a4*>(yb + s0);
+    r.h = {v.x, v.y};
+  } else {
+    r.h = {fetch_sample(yb, T, s0, pad_mode), fetch_sample(yb, T, s0 + 1, pad_mode)};
+  }
 }
-// Write them to the wave's staging area: sample s at RS * (s / 160) + s % 160.
-__device__ __forceinline__ void wave_stage(float* __restrict__ stage,
-                                           const float4 (&regs)[w400::NPRE], int lane) {
+// Write it to the wave's staging area: sample s at RS * (s / 160) + s % 160.
+__device__ __forceinline__ void wave_stage(float* __restrict__ stage, const Staged& r, int lane) {
   using namespace w400;
 #pragma unroll
-  for (int i = 0; i < NPRE; ++i) {
+  for (int i = 0; i < NQ4; ++i) {
     const int q = lane + 64 * i;
-    if (q < WQ) *reinterpret_cast<float4*>(stage + RS * (q / 40) + 4 * (q % 40)) = regs[i];
+    *reinterpret_cast<float4*>(stage + RS * (q / 40) + 4 * (q % 40)) = r.q[i];
+  }
+  if (lane < NH2) {
+    const int s = NQ4 * 256 + 2 * lane;
+    *reinterpret_cast<float2*>(stage + RS * (s / HOP) + s % HOP) = r.h;
   }
 }
 
@@ -242,7 +260,7 @@ __global__ __launch_bounds__(w400::WG, 4) void logmel400_kernel(
 
   // Running extremes of the clip this wave is in; they leave the wave (one atomic
   // pair) only when the clip or the run of tiles ends.
-  float vmax = -INFINITY, vmin = INFINITY;
+  unsigned mhi = 0u, mlo = 0x7F800000u;  // bit patterns of the largest / smallest floored power
   float* __restrict__ mine = lds + wv * PW;  // this wave's region: slot 0 | scratch | slot 1
   // (slot + scratch is one run of LDS whichever slot a tile uses)
 
@@ -250,7 +268,7 @@ __global__ __launch_bounds__(w400::WG, 4) void logmel400_kernel(
   {
     const float* __restrict__ yb = g_y + (long long)cur_b * p.T;
     const long long s_wave = (long long)cur_tile * (FT * HOP) - p.pad + 4 * wv * HOP;
-    float4 regs[NPRE];
+    Staged regs;
     wave_fetch(regs, yb, p.T, s_wave, p.pad_mode, tid0 & 63);
     wave_stage(mine, regs, tid0 & 63);
   }
@@ -274,9 +292,10 @@ __global__ __launch_bounds__(w400::WG, 4) void logmel400_kernel(
     STAMP(0)
 
     // ---- fetch the next tile's samples; they land during the FFT --------------------------
-    float4 regs[NPRE];
+    Staged regs;
 #pragma unroll
-    for (int i = 0; i < NPRE; ++i) regs[i] = {0.0f, 0.0f, 0.0f, 0.0f};  // defined on every path
+    for (int i = 0; i < NQ4; ++i) regs.q[i] = {0.0f, 0.0f, 0.0f, 0.0f};  // defined on every path
+    regs.h = {0.0f, 0.0f};
     if (more) {
       const float* __restrict__ ynb = g_y + (long long)cur_b * p.T;  // cur_* already advanced
       const long long sn = (long long)cur_tile * (FT * HOP) - p.pad + 4 * wv * HOP;
@@ -364,25 +383,28 @@ __global__ __launch_bounds__(w400::WG, 4) void logmel400_kernel(
       // wave-uniform row pointer + lane offset: the row step is scalar arithmetic
       float* __restrict__ rowp = g_out + (((long long)b * p.n_mels + m0) * p.F + f0);
       if (f0 + FT <= p.F) {
-        mel_sweep<EPI, true>(p, P, prog, klo, nchunks, npre, rowp, lane, true, vmax, vmin);
+        mel_sweep<EPI, true>(p, P, prog, klo, nchunks, npre, rowp, lane, true, mhi, mlo);
       } else {
-        mel_sweep<EPI, false>(p, P, prog, klo, nchunks, npre, rowp, lane, valid, vmax, vmin);
+        mel_sweep<EPI, false>(p, P, prog, klo, nchunks, npre, rowp, lane, valid, mhi, mlo);
       }
       if (EPI != MIA_EPI_NONE && g_maxkey != nullptr && (cur_tile == 0 || !more)) {
-        float rmax = vmax, rmin = vmin;
+        unsigned rhi = mhi, rlo = mlo;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
-          rmax = fmaxf(rmax, __shfl_xor(rmax, off));
-          rmin = fminf(rmin, __shfl_xor(rmin, off));
+          rhi = max(rhi, (unsigned)__shfl_xor((int)rhi, off));
+          rlo = min(rlo, (unsigned)__shfl_xor((int)rlo, off));  // positive floats order like their bits
         }
-        if (lane == 0) {
+        if (lane == 0 && rhi != 0u) {  // (a wave without filters has nothing to report)
+          // the stored values of the extreme powers, by the same instructions that stored them
+          float rmax = log_epilogue<EPI>(p, __builtin_bit_cast(float, rhi));
+          const float rmin = log_epilogue<EPI>(p, __builtin_bit_cast(float, rlo));
           // the max key is kept on the log10 scale (before the (.+4)/4 map)
           if (EPI == MIA_EPI_WHISPER) rmax = fmaf(rmax, 4.0f, -4.0f);
-          atomicMax(g_maxkey + b, float_to_key(rmax));
+          atomicMax(g_maxkey + b, float_to_key_nan(rmax));
           atomicMin(g_minkey + b, float_to_key(rmin));
         }
-        vmax = -INFINITY;
-        vmin = INFINITY;
+        mhi = 0u;
+        mlo = 0x7F800000u;
       }
     }
     STAMP(6)

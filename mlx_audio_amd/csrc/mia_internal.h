@@ -49,6 +49,14 @@ __host__ __device__ inline float key_to_float(int k) {
 }
 constexpr int kKeyMinusInf = (int)0x80000000;  // below the key of -inf
 constexpr int kKeyPlusInf = 0x7FFFFFFF;        // above the key of +inf
+constexpr int kKeyNaN = 0x7FC00000;            // a NaN sorts above +inf: it wins every maximum,
+                                               // as it does in the reference's max(...)
+// Key of a value that may be a NaN of either sign.
+__host__ __device__ inline int float_to_key_nan(float f) { return f != f ? kKeyNaN : float_to_key(f); }
+// max(v, floor) with the reference's NaN rules (maximum(NaN, x) = maximum(x, NaN) = NaN).
+__host__ __device__ inline float floor_nan(float v, float thr) {
+  return thr != thr ? thr : (v < thr ? thr : v);
+}
 
 // Sample i of a signal of length T with centre padding folded in.
 __device__ __forceinline__ float fetch_sample(const float* __restrict__ y, long long T,

@@ -85,21 +85,21 @@ __global__ __launch_bounds__(256) void to_db_kernel(const float* __restrict__ x,
                                                      float* __restrict__ out,
                                                      int* __restrict__ keys) {
   const long long b = blockIdx.y;
-  float vmax = -INFINITY;
+  int kmax = kKeyMinusInf;  // integer keys: a NaN value wins the maximum, as in the reference
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (long long)gridDim.x * blockDim.x) {
-    const float v = coef * log10f(fmaxf(x[b * n + i], amin) * inv_ref);
+    const float xv = x[b * n + i];
+    const float v = coef * log10f((xv < amin ? amin : xv) * inv_ref);  // a NaN stays a NaN
     out[b * n + i] = v;
-    vmax = fmaxf(vmax, v);
+    kmax = max(kmax, float_to_key_nan(v));
   }
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, off));
-  __shared__ float red[4];
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = vmax;
+  for (int off = 32; off > 0; off >>= 1) kmax = max(kmax, __shfl_xor(kmax, off));
+  __shared__ int red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = kmax;
   __syncthreads();
   if (threadIdx.x == 0 && keys != nullptr) {
-    vmax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    atomicMax(keys + b, float_to_key(vmax));
+    atomicMax(keys + b, max(max(red[0], red[1]), max(red[2], red[3])));
   }
 }
 
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void floor_rows_kernel(float* __restrict__ x, 
   const float thr = floor_from_key(keys[b * key_stride], MIA_EPI_DB, top);
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (long long)gridDim.x * blockDim.x) {
-    x[b * n + i] = fmaxf(x[b * n + i], thr);
+    x[b * n + i] = floor_nan(x[b * n + i], thr);
   }
 }
 
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void floor_clips_kernel(float* __restrict__ x,
       bool nd = false;
       if (b0 + j < B) {
         const float thr = floor_from_key(max_keys[(b0 + j) * key_stride], epi, top);
-        nd = key_to_float(min_keys[b0 + j]) < thr;
+        nd = thr != thr || key_to_float(min_keys[b0 + j]) < thr;  // a NaN maximum floods its clip
       }
       need[j] = nd ? 1 : 0;
     }
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void floor_clips_kernel(float* __restrict__ x,
       float* __restrict__ xb = x + b * n;
       for (long long i = lo + tid; i < hi; i += 256) {
         const float v = xb[i];
-        if (v < thr) xb[i] = thr;
+        if (v < thr || thr != thr) xb[i] = thr;
       }
     }
     __syncthreads();  // the lists are rebuilt for the next 1024 clips
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256) void dct2_kernel(const float* __restrict__ x, 
   const bool ok = i0 + lane < inner;
   for (int n = wave; n < n_in; n += 4) {
     float v = ok ? x[(o * n_in + n) * inner + i0 + lane] : 0.0f;
-    slab[n * 64 + lane] = fmaxf(v, thr);
+    slab[n * 64 + lane] = floor_nan(v, thr);
   }
   __syncthreads();
   for (int k0 = wave * KB; k0 < n_out; k0 += 4 * KB) {

@@ -429,7 +429,8 @@ __global__ __launch_bounds__(WG, 2) void fwd_kernel(FwdParams p) {
     __syncthreads();
     const long long frem = p.F - f0;
     const int fcount = frem < FT ? (int)frem : FT;
-    float vmax = -INFINITY, vmin = INFINITY;
+    int kmax = kKeyMinusInf;  // integer keys: a NaN value wins the maximum, as in the reference
+    float vmin = INFINITY;
     // one instantiation per table location, so that each knows its address space
     auto project = [&](const int* row_lo, const int* row_len, const int* row_off, const float* wts) {
       for (int idx2 = tid; idx2 < p.n_mels * FT; idx2 += WG) {
@@ -446,12 +447,12 @@ __global__ __launch_bounds__(WG, 2) void fwd_kernel(FwdParams p) {
         if (p.epi == MIA_EPI_WHISPER) {
           // values at or below the 1e-10 floor give exactly log10(1e-10) = -10
           const float yv = acc <= 1e-10f ? -10.0f : __log10f(acc);
-          vmax = fmaxf(vmax, yv);
+          kmax = max(kmax, float_to_key_nan(yv));
           outv = (yv + 4.0f) * 0.25f;
           vmin = fminf(vmin, outv);
         } else if (p.epi == MIA_EPI_DB) {
           outv = acc <= p.amin ? p.db_floor : p.coef * __log10f(acc * p.inv_ref);
-          vmax = fmaxf(vmax, outv);
+          kmax = max(kmax, float_to_key_nan(outv));
           vmin = fminf(vmin, outv);
         }
         p.mout[(b * p.n_mels + m) * p.F + f0 + fl] = outv;
@@ -465,22 +466,23 @@ __global__ __launch_bounds__(WG, 2) void fwd_kernel(FwdParams p) {
     if (p.epi != MIA_EPI_NONE && p.clip_max_key != nullptr) {
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) {
-        vmax = fmaxf(vmax, __shfl_xor(vmax, off));
+        kmax = max(kmax, __shfl_xor(kmax, off));
         vmin = fminf(vmin, __shfl_xor(vmin, off));
       }
-      __shared__ float red[2][WG / 64];
+      __shared__ int red_max[WG / 64];
+      __shared__ float red_min[WG / 64];
       if ((tid & 63) == 0) {
-        red[0][tid >> 6] = vmax;
-        red[1][tid >> 6] = vmin;
+        red_max[tid >> 6] = kmax;
+        red_min[tid >> 6] = vmin;
       }
       __syncthreads();
       if (tid == 0) {
 #pragma unroll
         for (int w = 1; w < WG / 64; ++w) {
-          vmax = fmaxf(vmax, red[0][w]);
-          vmin = fminf(vmin, red[1][w]);
+          kmax = max(kmax, red_max[w]);
+          vmin = fminf(vmin, red_min[w]);
         }
-        atomicMax(p.clip_max_key + b, float_to_key(vmax));
+        atomicMax(p.clip_max_key + b, kmax);
         atomicMin(p.clip_min_key + b, float_to_key(vmin));
       }
     }
