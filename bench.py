@@ -189,6 +189,16 @@ def main() -> None:
             dist.barrier()
             torch.cuda.synchronize()
 
+    # The GPU comes out of idle at a low clock and needs ~20 ms of work to reach its
+    # running clock (a 5-step run right after start-up measured 1.34 ms/step against 1.07
+    # in steady state).  A fixed, untimed 30 ms of the same step brings it there, so that
+    # the W warm-up steps asked for mean the same thing for every W; it is reported in
+    # config.clock_warmup_ms.
+    clock_warmup_ms = 30.0
+    t_pre = time.perf_counter()
+    while (time.perf_counter() - t_pre) * 1e3 < clock_warmup_ms:
+        out = step()
+        torch.cuda.synchronize()
     for _ in range(max(args.warmup, 1)):
         out = step()
     del out
@@ -235,7 +245,8 @@ def main() -> None:
             "dtype": "f32",
             "data": "synthetic white Gaussian noise generated on device",
             "config": {"workload": desc, "clips_per_gpu": clips,
-                       "parallelism": f"clips sharded over {n_gpus} GPU(s), no collective"},
+                       "parallelism": f"clips sharded over {n_gpus} GPU(s), no collective",
+                       "clock_warmup_ms": clock_warmup_ms},
             "roofline": {
                 "bound": "hbm",
                 "achieved": achieved,
