@@ -127,7 +127,10 @@ int mia_overlap_add(const float* frames, const float* window, int64_t B, int64_t
                     void* stream);
 
 /* Inverse STFT = mia_irfft_frames + mia_overlap_add (primitives/stft.py:292-312).
- * `workspace` must hold mia_istft_workspace_bytes() bytes of device memory. */
+ * `workspace` must hold mia_istft_workspace_bytes() bytes of device memory.  For
+ * hop = n_fft / 4 with n_fft in {1024, 2048, 4096} both steps run in one launch that
+ * keeps the overlapping frames in LDS (same result bit for bit) and the workspace
+ * size is 0. */
 size_t mia_istft_workspace_bytes(const mia_plan* plan, int64_t B, int64_t F);
 int mia_istft(const mia_plan* plan, const void* spec, int64_t B, int64_t F,
               int64_t stride_b, int64_t stride_bin, int64_t stride_frame,

@@ -550,6 +550,7 @@ int mia_overlap_add(const float* frames, const float* window, int64_t B, int64_t
 
 size_t mia_istft_workspace_bytes(const mia_plan* plan, int64_t B, int64_t F) {
   if (!plan || B <= 0 || F <= 0) return 0;
+  if (mia::istft_fused_supported(plan->n_fft, plan->hop)) return 0;  // overlap kept in LDS
   return sizeof(float) * (size_t)B * (size_t)F * (size_t)plan->n_fft;
 }
 
@@ -557,6 +558,30 @@ int mia_istft(const mia_plan* plan, const void* spec, int64_t B, int64_t F, int6
               int64_t stride_bin, int64_t stride_frame, int64_t out_len, float scale, float* out,
               void* workspace, size_t workspace_bytes, void* stream) {
   MIA_REQUIRE(plan != nullptr, "null plan");
+  if (mia::istft_fused_supported(plan->n_fft, plan->hop)) {
+    MIA_REQUIRE(B >= 0 && F >= 0 && out_len >= 0, "negative shape");
+    MIA_REQUIRE((spec && out) || B == 0 || F == 0 || out_len == 0, "null buffer");
+    if (B == 0 || out_len == 0) return MIA_OK;
+    if (F == 0) {
+      MIA_CHECK_HIP(hipMemsetAsync(out, 0, sizeof(float) * (size_t)B * (size_t)out_len,
+                                   (hipStream_t)stream));
+      return MIA_OK;
+    }
+    InvParams p{};
+    p.spec = reinterpret_cast<const float2*>(spec);
+    p.B = B;
+    p.F = F;
+    p.sb = stride_b;
+    p.sk = stride_bin;
+    p.sf = stride_frame;
+    p.tw = plan->d_tw;
+    p.win = plan->d_window;
+    p.hop = plan->hop;
+    p.out_len = out_len;
+    p.scale = scale;
+    p.out = out;
+    return launch_istft_fused(plan, p, (hipStream_t)stream);
+  }
   MIA_REQUIRE(workspace_bytes >= mia_istft_workspace_bytes(plan, B, F),
               "workspace too small: %zu < %zu", workspace_bytes,
               mia_istft_workspace_bytes(plan, B, F));

@@ -142,10 +142,18 @@ struct InvParams {
   const float2* tw;
   float* frames;         // (B, F, N)
   int tiles;
+  // fused istft (inverse FFT + overlap-add) only
+  const float* win;
+  int hop, tiles_per_wg;
+  long long out_len;
+  float scale;
+  float* out;            // (B, out_len)
 };
 
 int launch_forward(const mia_plan* plan, const FwdParams& p, int mode, hipStream_t s);
 int launch_inverse(const mia_plan* plan, const InvParams& p, hipStream_t s);
+bool istft_fused_supported(int n_fft, int hop);
+int launch_istft_fused(const mia_plan* plan, const InvParams& p, hipStream_t s);
 int launch_init_keys(int* max_keys, int* min_keys, long long n, hipStream_t s);
 int launch_logmel400(const FwdParams& p, const W400Tables& tb, hipStream_t s);
 bool fft_size_supported(int n_fft);

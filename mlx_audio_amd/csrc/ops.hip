@@ -24,8 +24,8 @@ __global__ __launch_bounds__(256) void ola_kernel(const float* __restrict__ fram
   for (long long f = first; f <= last; ++f) {
     const int s = (int)(i - f * hop);
     const float w = win[s];
-    sum += w * fb[f * n_fft + s];
-    wsum += w * w;
+    sum = fmaf(w, fb[f * n_fft + s], sum);  // (spelled out: the fused inverse kernel must
+    wsum = fmaf(w, w, wsum);                // round exactly like this one)
   }
   out[b * out_len + i] = sum / fmaxf(wsum, 1e-8f) * scale;
 }

@@ -82,9 +82,199 @@ constexpr T0Slot t0_slot(int s) {
   return {true, i, R - 1 - i, 1 + 2 * i};
 }
 
+// Inverse real FFT of one frame by the group of T threads that owns `buf`.  `xs` points
+// at the frame's bin 0 (stride p.sk between bins); `sink(n, v)` receives the time samples
+// (x[2n], x[2n+1]) = v, already scaled by 1/N.  With `to_buf` the samples are instead left
+// in buf[n] (plain layout) once every thread of the group has read its last-pass inputs.
+// The bins a thread needs in pass 0: X[k_s], X[M - k_s] for its R0 slots, plus X[M/2].
+template <class C>
+struct FrameBins {
+  float2 xk[C::R0], xm[C::R0], xh;
+  bool ready = false;  // holds the bins of the frame to transform next
+};
+template <class C>
+__device__ __forceinline__ void fetch_bins(FrameBins<C>& fb, const InvParams& p,
+                                           const float2* __restrict__ xs, bool valid, int t) {
+  constexpr int M = C::M, R = C::R0, S0 = C::S0;
+  const bool t0 = (t == 0);
+#pragma unroll
+  for (int s = 0; s < R; ++s) {
+    // generic thread: k = t + S0*s; thread 0: its own table
+    const T0Slot ts = t0_slot<R>(s);
+    const int k = t0 ? ts.k_half * (S0 / 2) : t + S0 * s;
+    fb.xk[s] = {0.0f, 0.0f};
+    fb.xm[s] = {0.0f, 0.0f};
+    if (valid) {
+      fb.xk[s] = xs[(long long)k * p.sk];
+      fb.xm[s] = xs[(long long)(M - k) * p.sk];
+    }
+  }
+  fb.xh = {0.0f, 0.0f};
+  if (valid && t0) fb.xh = xs[(long long)(M / 2) * p.sk];
+}
+
+// `fb` holds this frame's bins on entry if fb.ready (else they are fetched here), and on
+// exit the bins of the frame at `xs_next` (fetched behind the last pass's LDS reads, so
+// that their latency hides behind the last butterflies and the stores).
+template <class C, bool TO_BUF, class Sink>
+__device__ __forceinline__ void inverse_frame(const InvParams& p, const float2* __restrict__ tw,
+                                              float2* __restrict__ buf,
+                                              const float2* __restrict__ xs, bool valid, int t,
+                                              FrameBins<C>& fb, const float2* __restrict__ xs_next,
+                                              bool valid_next, Sink sink) {
+  constexpr int M = C::M, T = C::T;
+  const bool t0 = (t == 0);
+  const float inv_m = 1.0f / float(M);
+  if (!fb.ready) fetch_bins<C>(fb, p, xs, valid, t);
+  {
+    // ---- pass 0: bins -> Z (split step) -> radix R0 -> LDS -------------------
+  {
+    constexpr int R = C::R0, S0 = C::S0;
+    float2 zk[R], zmk[R];
+#pragma unroll
+    for (int s = 0; s < R; ++s) {
+      // generic thread: k = t + S0*s; thread 0: table below
+      const T0Slot ts = t0_slot<R>(s);
+      const int k = t0 ? ts.k_half * (S0 / 2) : t + S0 * s;
+      float2 xk = fb.xk[s], xm = fb.xm[s];
+      if (k == 0) {  // the real transform ignores Im X[0] and Im X[M]
+        xk.y = 0.0f;
+        xm.y = 0.0f;
+      }
+      const float2 w = tw[k];
+      // E = (X[k] + conj X[M-k])/2, O = conj(w) (X[k] - conj X[M-k])/2,
+      // Z[k] = E + iO, Z[M-k] = conj(E) + i conj(O).  The 1/2 is folded
+      // into the final scale.
+      const float2 E = {xk.x + xm.x, xk.y - xm.y};
+      const float2 D = {xk.x - xm.x, xk.y + xm.y};
+      const float2 O = cmul_conj(D, w);
+      zk[s] = {E.x - O.y, E.y + O.x};
+      zmk[s] = {E.x + O.y, O.x - E.y};
+    }
+    float2 A[R], Bv[R];
+    // generic threads: A[s] = Z[t + S0 s], B[R-1-s] = Z[M - k_s]
+#pragma unroll
+    for (int s = 0; s < R; ++s) {
+      A[s] = zk[s];
+      Bv[R - 1 - s] = zmk[s];
+    }
+    if (t0) {
+      float2 A0[R], B0[R];
+      static_for<0, R>([&](auto sc) {
+        constexpr int s = decltype(sc)::value;
+        constexpr T0Slot ts = t0_slot<R>(s);
+        if constexpr (ts.b_side) {
+          B0[ts.zk] = zk[s];
+          B0[ts.zmk] = zmk[s];
+        } else {
+          A0[ts.zmk] = zmk[s];
+          A0[ts.zk] = zk[s];
+        }
+      });
+      // the self-paired bin M/2: Z = conj(X[M/2]) (times 2 for the folded 1/2)
+      const float2 xh = fb.xh;
+      const float2 zh = {2.0f * xh.x, -2.0f * xh.y};
+      if constexpr (R % 2 == 0) {
+        A0[R / 2] = zh;
+      } else {
+        B0[(R - 1) / 2] = zh;
+      }
+#pragma unroll
+      for (int s = 0; s < R; ++s) {
+        A[s] = A0[s];
+        Bv[s] = B0[s];
+      }
+    }
+    // inverse = swap(FFT(swap(.)))
+#pragma unroll
+    for (int s = 0; s < R; ++s) {
+      A[s] = {A[s].y, A[s].x};
+      Bv[s] = {Bv[s].y, Bv[s].x};
+    }
+    Dft<R>::run(A);
+    Dft<R>::run(Bv);
+    const int jA = t;
+    const int jB = t0 ? S0 / 2 : S0 - t;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int sa = (C::PADQ == R) ? jA * (R + 1) + r : C::pos(jA * R + r);
+      const int sb = (C::PADQ == R) ? jB * (R + 1) + r : C::pos(jB * R + r);
+      buf[sa] = A[r];
+      buf[sb] = Bv[r];
+    }
+  }
+  inv_group_sync<C>();
+
+  // ---- middle pass -----------------------------------------------------------
+  if constexpr (C::NPASS == 3) {
+    constexpr int R = C::R1, S = M / R, NB = S / T, NS = C::R0;
+    constexpr int TWS = 2 * (M / (NS * R));
+    float2 v[NB][R];
+#pragma unroll
+    for (int bb = 0; bb < NB; ++bb) {
+      const int j = t + bb * T;
+      const int jm = j % NS;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        float2 x = buf[C::template pos_strided<S>(j, r)];
+        if (r > 0) x = cmul(x, tw[jm * r * TWS]);
+        v[bb][r] = x;
+      }
+    }
+    inv_group_sync<C>();
+#pragma unroll
+    for (int bb = 0; bb < NB; ++bb) Dft<R>::run(v[bb]);
+#pragma unroll
+    for (int bb = 0; bb < NB; ++bb) {
+      const int j = t + bb * T;
+      const int base = (j / NS) * NS * R + (j % NS);
+#pragma unroll
+      for (int r = 0; r < R; ++r) buf[C::template pos_strided<NS>(base, r)] = v[bb][r];
+    }
+    inv_group_sync<C>();
+  }
+
+  // ---- last pass: outputs are time samples ------------------------------------
+  {
+    constexpr int R = C::RL, NS = M / R, NB = NS / T;
+    float2 v[NB][R];
+#pragma unroll
+    for (int bb = 0; bb < NB; ++bb) {
+      const int j = t + bb * T;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        float2 x = buf[C::template pos_strided<NS>(j, r)];
+        if (r > 0) x = cmul(x, tw[2 * j * r]);
+        v[bb][r] = x;
+      }
+    }
+    inv_group_sync<C>();  // buf is free again
+    fb.ready = xs_next != nullptr;
+    if (fb.ready) fetch_bins<C>(fb, p, xs_next, valid_next, t);
+#pragma unroll
+    for (int bb = 0; bb < NB; ++bb) Dft<R>::run(v[bb]);
+    const float sc = 0.5f * inv_m;
+#pragma unroll
+    for (int bb = 0; bb < NB; ++bb) {
+      const int j = t + bb * T;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        // swap back: x[2n] = Re z[n] = v.y, x[2n+1] = Im z[n] = v.x
+        const float2 o = {v[bb][r].y * sc, v[bb][r].x * sc};
+        if constexpr (TO_BUF) {
+          buf[j + r * NS] = o;
+        } else {
+          sink(j + r * NS, o);
+        }
+      }
+    }
+  }
+  }
+}
+
 template <class C, int WG, int ITERS>
 __global__ __launch_bounds__(WG) void inv_kernel(InvParams p) {
-  constexpr int M = C::M, T = C::T, N = C::N;
+  constexpr int N = C::N;
   constexpr int G = C::template groups<WG>();
   constexpr int FT = G * ITERS;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -99,159 +289,177 @@ __global__ __launch_bounds__(WG) void inv_kernel(InvParams p) {
   const int tile = blockIdx.x % p.tiles;
   const long long f0 = (long long)tile * FT;
   const float2* __restrict__ tw = p.tw;
-  const bool t0 = (t == 0);
-  const float inv_m = 1.0f / float(M);
 
   if (!active) return;
+  FrameBins<C> fb;
   for (int it = 0; it < ITERS; ++it) {
     const long long f = f0 + it * G + g;
     const bool valid = f < p.F;
-    if (!C::MULTIWAVE && !valid) continue;
+    if (!C::MULTIWAVE && !valid) break;  // later frames of this group do not exist either
     const float2* __restrict__ xs = p.spec + b * p.sb + (valid ? f : 0) * p.sf;
+    float2* __restrict__ orow =
+        reinterpret_cast<float2*>(p.frames + (b * p.F + (valid ? f : 0)) * (long long)N);
+    // (no prefetch of the next frame's bins here: it pushes the 4096-point plan past
+    // 256 VGPRs, measured 2.43 against 2.24 ms on the round-trip workload)
+    fb.ready = false;
+    inverse_frame<C, false>(p, tw, buf, xs, valid, t, fb, nullptr, false,
+                            [&](int n, float2 v) {
+                              if (valid) orow[n] = v;
+                            });
+  }
+}
 
-    // ---- pass 0: bins -> Z (split step) -> radix R0 -> LDS -------------------
-    {
-      constexpr int R = C::R0, S0 = C::S0;
-      float2 zk[R], zmk[R];
+// Fused istft for hop = n_fft / 4 with hop a multiple of the workgroup size: inverse FFT
+// + windowed overlap-add + normalisation by the window envelope, no frame workspace.
+// A persistent workgroup walks a contiguous run of FT-frame tiles; within a row it
+// carries the n_fft - hop samples that later frames still add to in an LDS ring, and
+// when it starts in the middle of a row it first re-transforms (without storing) the
+// tile whose frames reach into its run.  Thread `tid` only ever touches samples
+// q = tid (mod WG), whose position inside any frame is also tid (mod WG): its N / WG
+// window taps and its hop / WG envelope values live in registers.  Every output sample
+// receives its frames in ascending order with the arithmetic of ola_kernel
+// (fma(w, x, sum), fma(w, w, wsum), sum / max(wsum, 1e-8) * scale), so the result equals
+// the two-kernel path bit for bit.
+template <class C, int WG, int ITERS>
+__global__ __launch_bounds__(WG) void istft_kernel(InvParams p) {
+  constexpr int N = C::N, HOP = N / 4;
+  constexpr int G = C::template groups<WG>();
+  constexpr int FT = G * ITERS;
+  constexpr int NW = N / WG;        // window taps per thread
+  constexpr int HW = HOP / WG;      // envelope values per thread
+  constexpr int SPAN = FT * HOP;    // samples a tile completes
+  constexpr int RING = SPAN + N;    // accumulator length
+  constexpr int QW = (G - 1) * HW + NW;  // accumulator slots per thread and iteration
+  static_assert(HOP % WG == 0 && HW >= 1, "hop must be a multiple of the workgroup size");
+  static_assert(FT >= 3, "one warm-up tile must cover the three frames that reach into a run");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float2* bufs = reinterpret_cast<float2*>(smem_raw);
+  float* acc = reinterpret_cast<float*>(bufs + G * C::LBUF);
+
+  const int tid = threadIdx.x;
+  int g, t;
+  bool active;
+  C::map(tid, g, t, active);
+  float2* buf = bufs + (active ? g : 0) * C::LBUF;
+  const float2* __restrict__ tw = p.tw;
+  const float* __restrict__ win = p.win;
+
+  const long long total = p.B * p.tiles;
+  const long long first = (long long)blockIdx.x * p.tiles_per_wg;
+  const long long last = first + p.tiles_per_wg < total ? first + p.tiles_per_wg : total;
+  if (first >= last) return;
+
+  float wreg[NW];  // win[tid + j WG]
 #pragma unroll
-      for (int s = 0; s < R; ++s) {
-        // generic thread: k = t + S0*s; thread 0: table below
-        const T0Slot ts = t0_slot<R>(s);
-        const int k = t0 ? ts.k_half * (S0 / 2) : t + S0 * s;
-        float2 xk = {0.0f, 0.0f}, xm = {0.0f, 0.0f};
-        if (valid) {
-          xk = xs[(long long)k * p.sk];
-          xm = xs[(long long)(M - k) * p.sk];
-        }
-        if (k == 0) {  // the real transform ignores Im X[0] and Im X[M]
-          xk.y = 0.0f;
-          xm.y = 0.0f;
-        }
-        const float2 w = tw[k];
-        // E = (X[k] + conj X[M-k])/2, O = conj(w) (X[k] - conj X[M-k])/2,
-        // Z[k] = E + iO, Z[M-k] = conj(E) + i conj(O).  The 1/2 is folded
-        // into the final scale.
-        const float2 E = {xk.x + xm.x, xk.y - xm.y};
-        const float2 D = {xk.x - xm.x, xk.y + xm.y};
-        const float2 O = cmul_conj(D, w);
-        zk[s] = {E.x - O.y, E.y + O.x};
-        zmk[s] = {E.x + O.y, O.x - E.y};
-      }
-      float2 A[R], Bv[R];
-      // generic threads: A[s] = Z[t + S0 s], B[R-1-s] = Z[M - k_s]
+  for (int j = 0; j < NW; ++j) wreg[j] = win[tid + j * WG];
+  // envelope of a sample whose four frames all exist: sum of w^2 over s = r + c hop,
+  // c = 3..0 (ascending frames = descending position in the frame), r = tid + m WG
+  float wsq[HW];
 #pragma unroll
-      for (int s = 0; s < R; ++s) {
-        A[s] = zk[s];
-        Bv[R - 1 - s] = zmk[s];
-      }
-      if (t0) {
-        float2 A0[R], B0[R];
-        static_for<0, R>([&](auto sc) {
-          constexpr int s = decltype(sc)::value;
-          constexpr T0Slot ts = t0_slot<R>(s);
-          if constexpr (ts.b_side) {
-            B0[ts.zk] = zk[s];
-            B0[ts.zmk] = zmk[s];
-          } else {
-            A0[ts.zmk] = zmk[s];
-            A0[ts.zk] = zk[s];
-          }
-        });
-        // the self-paired bin M/2: Z = conj(X[M/2]) (times 2 for the folded 1/2)
-        float2 xh = {0.0f, 0.0f};
-        if (valid) xh = xs[(long long)(M / 2) * p.sk];
-        const float2 zh = {2.0f * xh.x, -2.0f * xh.y};
-        if constexpr (R % 2 == 0) {
-          A0[R / 2] = zh;
+  for (int m = 0; m < HW; ++m) {
+    float ws = 0.0f;
+#pragma unroll
+    for (int c = 3; c >= 0; --c) ws = fmaf(wreg[m + c * HW], wreg[m + c * HW], ws);
+    wsq[m] = ws;
+  }
+
+  // one warm-up tile when the run starts in the middle of a row
+  long long idx = (first % p.tiles) > 0 ? first - 1 : first;
+  // The accumulator is a ring: `origin` is the slot of the tile's first sample; a slot
+  // is cleared when its sample is stored, which makes it the far end of the ring.
+  for (int q = tid; q < RING; q += WG) acc[q] = 0.0f;
+  int origin = 0;
+  auto slot = [&](int q) {
+    const int s = origin + q;
+    return s >= RING ? s - RING : s;
+  };
+  __syncthreads();
+
+  FrameBins<C> fb;
+  for (; idx < last; ++idx) {
+    const long long b = idx / p.tiles;
+    const int tile = (int)(idx - b * p.tiles);
+    const long long f0 = (long long)tile * FT;
+    const int nf = p.F - f0 < FT ? (int)(p.F - f0) : FT;  // frames of this tile that exist
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+      // ---- every group transforms one frame into its own buffer ------------------------
+      if (active) {
+        const bool valid = it * G + g < nf;
+        if (C::MULTIWAVE || valid) {
+          const float2* __restrict__ xs = p.spec + b * p.sb + (valid ? f0 + it * G + g : 0) * p.sf;
+          // (no prefetch of the next frame's bins: with the window taps resident it would
+          // take the kernel past 256 VGPRs)
+          fb.ready = false;
+          inverse_frame<C, true>(p, tw, buf, xs, valid, t, fb, nullptr, false, [](int, float2) {});
         } else {
-          B0[(R - 1) / 2] = zh;
-        }
-#pragma unroll
-        for (int s = 0; s < R; ++s) {
-          A[s] = A0[s];
-          Bv[s] = B0[s];
+          fb.ready = false;
         }
       }
-      // inverse = swap(FFT(swap(.)))
+      __syncthreads();  // also orders the previous tile's clearing stores before the adds below
+      // ---- add the G frames to the accumulator, earliest frame first -------------------
 #pragma unroll
-      for (int s = 0; s < R; ++s) {
-        A[s] = {A[s].y, A[s].x};
-        Bv[s] = {Bv[s].y, Bv[s].x};
-      }
-      Dft<R>::run(A);
-      Dft<R>::run(Bv);
-      const int jA = t;
-      const int jB = t0 ? S0 / 2 : S0 - t;
+      for (int k = 0; k < QW; ++k) {
+        const int a = slot(it * G * HOP + tid + k * WG);
+        float sum = acc[a];
 #pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const int sa = (C::PADQ == R) ? jA * (R + 1) + r : C::pos(jA * R + r);
-        const int sb = (C::PADQ == R) ? jB * (R + 1) + r : C::pos(jB * R + r);
-        buf[sa] = A[r];
-        buf[sb] = Bv[r];
-      }
-    }
-    inv_group_sync<C>();
-
-    // ---- middle pass -----------------------------------------------------------
-    if constexpr (C::NPASS == 3) {
-      constexpr int R = C::R1, S = M / R, NB = S / T, NS = C::R0;
-      constexpr int TWS = 2 * (M / (NS * R));
-      float2 v[NB][R];
-#pragma unroll
-      for (int bb = 0; bb < NB; ++bb) {
-        const int j = t + bb * T;
-        const int jm = j % NS;
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-          float2 x = buf[C::template pos_strided<S>(j, r)];
-          if (r > 0) x = cmul(x, tw[jm * r * TWS]);
-          v[bb][r] = x;
-        }
-      }
-      inv_group_sync<C>();
-#pragma unroll
-      for (int bb = 0; bb < NB; ++bb) Dft<R>::run(v[bb]);
-#pragma unroll
-      for (int bb = 0; bb < NB; ++bb) {
-        const int j = t + bb * T;
-        const int base = (j / NS) * NS * R + (j % NS);
-#pragma unroll
-        for (int r = 0; r < R; ++r) buf[C::template pos_strided<NS>(base, r)] = v[bb][r];
-      }
-      inv_group_sync<C>();
-    }
-
-    // ---- last pass: outputs are time samples ------------------------------------
-    {
-      constexpr int R = C::RL, NS = M / R, NB = NS / T;
-      float2 v[NB][R];
-#pragma unroll
-      for (int bb = 0; bb < NB; ++bb) {
-        const int j = t + bb * T;
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-          float2 x = buf[C::template pos_strided<NS>(j, r)];
-          if (r > 0) x = cmul(x, tw[2 * j * r]);
-          v[bb][r] = x;
-        }
-      }
-      inv_group_sync<C>();  // next iteration overwrites buf
-#pragma unroll
-      for (int bb = 0; bb < NB; ++bb) Dft<R>::run(v[bb]);
-      if (valid) {
-        float2* __restrict__ orow =
-            reinterpret_cast<float2*>(p.frames + (b * p.F + f) * (long long)N);
-        const float sc = 0.5f * inv_m;
-#pragma unroll
-        for (int bb = 0; bb < NB; ++bb) {
-          const int j = t + bb * T;
-#pragma unroll
-          for (int r = 0; r < R; ++r) {
-            // swap back: x[2n] = Re z[n] = v.y, x[2n+1] = Im z[n] = v.x
-            orow[j + r * NS] = {v[bb][r].y * sc, v[bb][r].x * sc};
+        for (int gg = 0; gg < G; ++gg) {
+          const int j = k - gg * HW;  // the sample is tap tid + j WG of frame gg
+          if (j >= 0 && j < NW && it * G + gg < nf) {
+            const float* __restrict__ fr = reinterpret_cast<const float*>(bufs + gg * C::LBUF);
+            sum = fmaf(wreg[j], fr[tid + j * WG], sum);
           }
         }
+        acc[a] = sum;
       }
+      __syncthreads();
+    }
+    // ---- the first SPAN samples are complete (all of them at the end of a row):
+    // normalise, store, clear ---------------------------------------------------------------
+    const long long base = f0 * HOP;  // output position of the tile's first sample
+    const bool row_end = tile == p.tiles - 1;
+    const long long left = p.out_len - base;  // samples of the row from `base` on
+    float* __restrict__ orow = p.out + b * p.out_len + base;
+    if (!row_end && f0 >= 3 && nf == FT && left >= SPAN) {
+      // every sample of the span has its four frames: envelope from registers
+#pragma unroll
+      for (int k = 0; k < SPAN / WG; ++k) {
+        const int a = slot(tid + k * WG);
+        const float sum = acc[a];
+        acc[a] = 0.0f;
+        if (idx >= first) orow[tid + k * WG] = sum / fmaxf(wsq[k % HW], 1e-8f) * p.scale;
+      }
+    } else {
+      const int avail = row_end ? RING : SPAN;
+      const int count = left < avail ? (left < 0 ? 0 : (int)left) : avail;
+      for (int q = tid; q < avail; q += WG) {
+        const int a = slot(q);
+        const float sum = acc[a];
+        acc[a] = 0.0f;
+        if (q < count && idx >= first) {
+          // frames f0 + fa .. f0 + fb contain this sample (relative to the tile, may be < 0)
+          int fa = q - N + 1;
+          fa = fa <= 0 ? -((-fa) / HOP) : (fa + HOP - 1) / HOP;
+          if (f0 + fa < 0) fa = (int)-f0;
+          int fbx = q / HOP;
+          if (f0 + fbx > p.F - 1) fbx = (int)(p.F - 1 - f0);
+          float wsum = 0.0f;
+          for (int f = fa; f <= fbx; ++f) {
+            const float w = win[q - f * HOP];
+            wsum = fmaf(w, w, wsum);
+          }
+          orow[q] = sum / fmaxf(wsum, 1e-8f) * p.scale;
+        }
+      }
+    }
+    if (row_end) {
+      // anything past the accumulator is beyond the last frame: zeros
+      if (idx >= first) {
+        for (long long i = base + RING + tid; i < p.out_len; i += WG) p.out[b * p.out_len + i] = 0.0f;
+      }
+      origin = 0;
+    } else {
+      origin = slot(SPAN);
     }
   }
 }
@@ -287,6 +495,58 @@ static int launch_inv(const InvParams& p0, hipStream_t s) {
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(WG), lds, s, p);
   MIA_CHECK_HIP(hipGetLastError());
   return MIA_OK;
+}
+
+template <class C, int WG, int ITERS>
+static int launch_fused(const InvParams& p0, hipStream_t s) {
+  constexpr int G = C::template groups<WG>();
+  constexpr int FT = G * ITERS;
+  InvParams p = p0;
+  p.tiles = (int)((p.F + FT - 1) / FT);
+  const long long total = p.B * p.tiles;
+  if (total <= 0) return MIA_OK;
+  constexpr size_t lds = sizeof(float2) * G * C::LBUF + sizeof(float) * ((size_t)FT * (C::N / 4) + C::N);
+  static_assert(lds <= 80 * 1024, "two workgroups per CU");
+  auto kern = istft_kernel<C, WG, ITERS>;
+  if (lds > 64 * 1024) {
+    MIA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  }
+  int dev = 0, cus = 256, per_cu = 1;
+  MIA_CHECK_HIP(hipGetDevice(&dev));
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), WG,
+                                                   lds) != hipSuccess || per_cu < 1) {
+    per_cu = 1;
+  }
+  long long grid = (long long)cus * per_cu;
+  if (grid > total) grid = total;
+  const long long per_wg = (total + grid - 1) / grid;
+  if (per_wg > 0x7fffffffLL) {
+    set_error("batch too large for one launch: %lld tiles (split the batch)", total);
+    return MIA_ERR_UNSUPPORTED;
+  }
+  p.tiles_per_wg = (int)per_wg;
+  grid = (total + per_wg - 1) / per_wg;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WG), lds, s, p);
+  MIA_CHECK_HIP(hipGetLastError());
+  return MIA_OK;
+}
+
+// The framings the fused kernel covers: hop = n_fft / 4 with hop a multiple of 256.
+bool istft_fused_supported(int n_fft, int hop) {
+  return (n_fft == 1024 || n_fft == 2048 || n_fft == 4096) && hop * 4 == n_fft;
+}
+
+int launch_istft_fused(const mia_plan* plan, const InvParams& p, hipStream_t s) {
+  switch (plan->n_fft) {
+    case 1024: return launch_fused<Inv1024, 256, 2>(p, s);
+    case 2048: return launch_fused<Inv2048, 256, 2>(p, s);
+    case 4096: return launch_fused<Inv4096, 256, 2>(p, s);
+    default:
+      set_error("n_fft=%d has no fused inverse", plan->n_fft);
+      return MIA_ERR_UNSUPPORTED;
+  }
 }
 
 int launch_inverse(const mia_plan* plan, const InvParams& p, hipStream_t s) {

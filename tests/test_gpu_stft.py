@@ -201,3 +201,44 @@ def test_magnitude_phase(gpu):
     zt = torch.from_numpy(z).to(gpu)
     np.testing.assert_allclose(magnitude(zt).cpu().numpy(), np.abs(z), rtol=1e-6)
     np.testing.assert_allclose(phase(zt).cpu().numpy(), np.angle(z), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("n_fft,B,F", [
+    (4096, 2, 2801),   # HTDemucs framing; more tiles than workgroups: runs start mid-row
+    (4096, 3, 2),      # rows shorter than one tile
+    (2048, 3, 4099),
+    (1024, 5, 12345),
+    (1024, 1, 1),
+])
+def test_fused_istft_equals_two_kernel_path(gpu, n_fft, B, F):
+    """For hop = n_fft / 4 mia_istft is one launch that keeps the overlapping frames in LDS:
+    it must equal mia_irfft_frames + mia_overlap_add bit for bit, including rows cut
+    between workgroups and output lengths that stop short of / run past the last frame."""
+    from mlx_audio_amd import _lib
+    from mlx_audio_amd._runtime import get_plan, stream_ptr
+    from mlx_audio_amd.primitives.stft import padded_window_np
+
+    lib = _lib.lib()
+    hop = n_fft // 4
+    gen = torch.Generator(device=gpu)
+    gen.manual_seed(n_fft + F)
+    bins = n_fft // 2 + 1
+    spec = torch.view_as_complex(torch.randn((B, F, bins, 2), generator=gen, device=gpu))
+    win = padded_window_np("hann", n_fft, n_fft)
+    plan = get_plan(spec.device, n_fft, hop, True, "constant", win)
+    assert lib.mia_istft_workspace_bytes(plan.handle, B, F) == 0
+    win_d = torch.from_numpy(np.array(win, dtype=np.float32)).to(gpu)
+    frames = torch.empty((B, F, n_fft), dtype=torch.float32, device=gpu)
+    sb, sf, sk = spec.stride()
+    full = n_fft + (F - 1) * hop
+    for out_len in (full, full - hop // 2 - 3, full + 777):
+        with torch.cuda.device(spec.device):
+            _lib.check(lib.mia_irfft_frames(plan.handle, spec.data_ptr(), B, F, sb, sk, sf,
+                                            frames.data_ptr(), stream_ptr(spec.device)))
+            ref = torch.empty((B, out_len), dtype=torch.float32, device=gpu)
+            _lib.check(lib.mia_overlap_add(frames.data_ptr(), win_d.data_ptr(), B, F, n_fft, hop,
+                                           out_len, 0.5, ref.data_ptr(), stream_ptr(spec.device)))
+            got = torch.full((B, out_len), float("nan"), dtype=torch.float32, device=gpu)
+            _lib.check(lib.mia_istft(plan.handle, spec.data_ptr(), B, F, sb, sk, sf, out_len, 0.5,
+                                     got.data_ptr(), None, 0, stream_ptr(spec.device)))
+        assert torch.equal(got, ref), (out_len, float((got - ref).abs().max()))
