@@ -315,10 +315,120 @@ __global__ __launch_bounds__(256) void dct2_kernel(const float* __restrict__ x, 
   }
 }
 
+// The same product on the matrix cores, for n_in <= 128 and n_out <= 48 (MFCC: 128 mel
+// bands -> 40 coefficients): out = basis (n_out x n_in) . max(x, floor) (n_in x 64 positions)
+// per tile, v_mfma_f32_16x16x4_f32 (exact fp32 products, fp32 accumulation).  Persistent
+// workgroups: wave w owns positions 16 w .. 16 w + 15 of every tile and keeps the A
+// operands of all three 16-row blocks of the basis in registers for its whole run
+//   A(mb, ks): lane l holds basis[16 mb + l % 16][4 ks + l / 16]   (0 outside the matrix)
+//   B(ks)    : lane l holds x[4 ks + l / 16][16 w + l % 16]         (from the LDS slab)
+//   D(mb)    : lane l holds rows 16 mb + 4 (l / 16) + r, r = 0..3, of position 16 w + l % 16
+typedef float dct_floatx4 __attribute__((ext_vector_type(4)));
+constexpr int kDctMB = 3, kDctKS = 32;  // 48 rows, 128 taps
+__global__ __launch_bounds__(256) void dct2_mfma_kernel(const float* __restrict__ x, int n_in,
+                                                         long long inner,
+                                                         const float* __restrict__ basis, int n_out,
+                                                         float* __restrict__ out,
+                                                         const int* __restrict__ keys,
+                                                         long long key_stride, float top,
+                                                         long long tiles_per_row, long long total,
+                                                         int tiles_per_wg) {
+  __shared__ float slab[128 * 64];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int row = lane & 15, kq = lane >> 4;
+  float a[kDctMB][kDctKS];
+#pragma unroll
+  for (int mb = 0; mb < kDctMB; ++mb) {
+#pragma unroll
+    for (int ks = 0; ks < kDctKS; ++ks) {
+      const int m = 16 * mb + row, k = 4 * ks + kq;
+      a[mb][ks] = (m < n_out && k < n_in) ? basis[(long long)m * n_in + k] : 0.0f;
+    }
+  }
+  const long long first = (long long)blockIdx.x * tiles_per_wg;
+  const long long last = first + tiles_per_wg < total ? first + tiles_per_wg : total;
+  // The tile's inputs are fetched one tile ahead into registers (they fly during the
+  // MFMAs of the current tile) and reach the slab, floored, after its last reader.
+  float nx[32];
+  int nkey = 0;  // the clip's maximum key travels with the prefetch
+  auto fetch = [&](long long idx_n) {
+    const long long o = idx_n / tiles_per_row;
+    if (keys && idx_n < last) nkey = keys[o * key_stride];
+    const long long i0 = (idx_n - o * tiles_per_row) * 64;
+    const bool ok = idx_n < last && i0 + lane < inner;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+      const int n = wave + 4 * j;
+      nx[j] = (ok && n < n_in) ? x[(o * n_in + n) * inner + i0 + lane] : 0.0f;
+    }
+  };
+  fetch(first);
+  for (long long idx = first; idx < last; ++idx) {
+    const long long o = idx / tiles_per_row;
+    const long long i0 = (idx - o * tiles_per_row) * 64;
+    const float thr = keys ? floor_from_key(nkey, MIA_EPI_DB, top) : -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+      const int n = wave + 4 * j;
+      slab[n * 64 + lane] = n < n_in ? floor_nan(nx[j], thr) : 0.0f;
+    }
+    __syncthreads();
+    fetch(idx + 1);
+    float bv[kDctKS];
+#pragma unroll
+    for (int ks = 0; ks < kDctKS; ++ks) bv[ks] = slab[(4 * ks + kq) * 64 + 16 * wave + row];
+    dct_floatx4 acc[kDctMB];
+#pragma unroll
+    for (int mb = 0; mb < kDctMB; ++mb) acc[mb] = dct_floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int ks = 0; ks < kDctKS; ++ks) {
+#pragma unroll
+      for (int mb = 0; mb < kDctMB; ++mb) {
+        acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb][ks], bv[ks], acc[mb], 0, 0, 0);
+      }
+    }
+    // The prefetched inputs are waited for HERE, behind the MFMAs and before this tile's
+    // stores: waited for at the top of the loop, the in-order counter would also wait for
+    // the acknowledgements of these stores.
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+    const long long pos = i0 + 16 * wave + row;
+    if (pos < inner) {
+#pragma unroll
+      for (int mb = 0; mb < kDctMB; ++mb) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = 16 * mb + 4 * kq + r;
+          if (m < n_out) out[(o * n_out + m) * inner + pos] = acc[mb][r];
+        }
+      }
+    }
+    __syncthreads();  // the next tile overwrites the slab
+  }
+}
+
 int launch_dct2(const float* x, long long outer, int n_in, long long inner, const float* basis,
                 int n_out, float* out, const int* keys, long long key_stride, float top,
                 hipStream_t s) {
   if (outer <= 0 || inner <= 0 || n_out <= 0) return MIA_OK;
+  if (n_in <= 4 * kDctKS && n_out <= 16 * kDctMB && n_in >= 32) {
+    const long long tiles_per_row = (inner + 63) / 64;
+    const long long total = outer * tiles_per_row;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+      (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    }
+    long long grid = 2LL * cus;  // 32 KB of LDS, < 256 VGPRs: two workgroups per CU
+    if (grid > total) grid = total;
+    const long long per_wg = (total + grid - 1) / grid;
+    if (per_wg <= 0x7fffffffLL) {
+      grid = (total + per_wg - 1) / per_wg;
+      hipLaunchKernelGGL(dct2_mfma_kernel, dim3((unsigned)grid), dim3(256), 0, s, x, n_in, inner,
+                         basis, n_out, out, keys, key_stride, top, tiles_per_row, total, (int)per_wg);
+      MIA_CHECK_HIP(hipGetLastError());
+      return MIA_OK;
+    }
+  }
   const size_t lds = sizeof(float) * 64 * (size_t)n_in;
   if (lds > 160 * 1024) {
     set_error("dct: n_in=%d too large for the LDS slab", n_in);
