@@ -12,6 +12,7 @@ Workloads (config.workload):
   clap64      1024 x 10 s @48 kHz -> (1024, 1001, 64) dB mel
   mfcc40      1024 x 30 s @16 kHz, n_fft 2048 / hop 512 / 128 mels -> 40 MFCC
   htdemucs    16 stereo x 60 s @44.1 kHz STFT+iSTFT round trip, n_fft 4096 / hop 1024
+  resample    512 x 30 s @44.1 kHz -> 16 kHz, polyphase (up 160 / down 441)
 """
 
 from __future__ import annotations
@@ -34,7 +35,7 @@ def make_workload(name: str, clips: int, device, seed: int):
     import torch
 
     from mlx_audio_amd.frontends import clap_log_mel, compute_log_mel_spectrogram
-    from mlx_audio_amd.primitives import istft, mfcc, stft
+    from mlx_audio_amd.primitives import istft, mfcc, resample_poly, stft
 
     gen = torch.Generator(device=device)
     gen.manual_seed(seed)
@@ -77,14 +78,22 @@ def make_workload(name: str, clips: int, device, seed: int):
         return (step, rows / 2 * 60.0 / 3600.0, abytes,
                 f"HTDemucs STFT+iSTFT round trip, {rows // 2} stereo x 60 s @44.1 kHz, "
                 "n_fft 4096 hop 1024", "STFT round-trip track-hours/sec (n_fft 4096)")
+    if name == "resample":
+        T = 44100 * 30
+        y = torch.randn((clips, T), generator=gen, device=device, dtype=torch.float32)
+        abytes = clips * (T * 4 + 480000 * 4)
+        return (lambda: resample_poly(y, 16000, 44100), clips * 30.0 / 3600.0, abytes,
+                f"polyphase resampling 44.1 kHz -> 16 kHz (up 160, down 441, 56 taps per "
+                f"output), {clips} x 30 s clips", "resample_poly audio-hours/sec (44.1k -> 16k)")
     raise SystemExit(f"unknown workload {name}")
 
 
 KERNEL_OF = {
     "whisper128": "logmel400_kernel (fused pad+frame+window+rFFT-400+128-mel+log10)",
     "clap64": "fwd_kernel<1024, mel> (fused pad+frame+window+rFFT+mel+dB)",
-    "mfcc40": "fwd_kernel<2048, mel> (fused rFFT+mel+dB) followed by dct2_kernel",
-    "htdemucs": "fwd_kernel<4096> then inv_kernel<4096> + ola_kernel",
+    "mfcc40": "fwd_kernel<2048, mel> (fused rFFT+mel+dB) followed by dct2_mfma_kernel",
+    "htdemucs": "fwd_kernel<4096> then istft_kernel<4096> (fused inverse FFT + overlap-add)",
+    "resample": "upfirdn_kernel (polyphase FIR, input span and phase table staged in LDS)",
 }
 
 
@@ -179,7 +188,8 @@ def main() -> None:
         print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: launch with "
               "torch.distributed.run for N>1", file=sys.stderr)
 
-    default_clips = {"whisper128": 1024, "clap64": 1024, "mfcc40": 1024, "htdemucs": 32}
+    default_clips = {"whisper128": 1024, "clap64": 1024, "mfcc40": 1024, "htdemucs": 32,
+                     "resample": 512}
     clips = args.clips or default_clips.get(args.workload, 1024)
     step, units, abytes, desc, metric = make_workload(args.workload, clips, device, 1234 + rank)
 

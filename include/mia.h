@@ -186,6 +186,32 @@ int mia_dct2(const float* x, int64_t outer, int n_in, int64_t inner, const float
 int mia_magnitude(const void* z, int64_t n, float* out, void* stream);
 int mia_phase(const void* z, int64_t n, float* out, void* stream);
 
+/* ---- sample-rate conversion (primitives/resample.py) -------------------------------
+ * Padding modes of the polyphase filter (the `padtype` values of resample_poly,
+ * primitives/resample.py:213-214, that extend the signal by copying samples). */
+#define MIA_RS_PAD_CONSTANT 0
+#define MIA_RS_PAD_EDGE 1
+#define MIA_RS_PAD_REFLECT 2
+#define MIA_RS_PAD_SYMMETRIC 3
+#define MIA_RS_PAD_WRAP 4
+/* resample_poly (primitives/resample.py:209-302, which hands float32 rows to
+ * scipy.signal.resample_poly at :275): upsample by `up`, FIR-filter, keep every `down`-th
+ * sample.  x: device (rows, n_in).  phase_table: device (up, taps_per_phase), row t = the
+ * taps of phase t, oldest input sample first (the zero-padded filter h, h[(P-1-j)*up + t]).
+ * Output o is the float32 sum over j, in order, of x[q/up - P + 1 + j] * table[q%up][j]
+ * with q = (o + skip) * down; `skip` = outputs of the full convolution dropped in front
+ * (the filter's delay).  out: device (rows, n_out).  Bit-identical to SciPy's float32 path. */
+int mia_upfirdn(const float* x, int64_t rows, int64_t n_in, const float* phase_table, int up,
+                int down, int taps_per_phase, int64_t skip, int64_t n_out, int pad_mode, float* out,
+                void* stream);
+/* resample(res_type="linear") (primitives/resample.py:171-196): out[r,i] =
+ * float(((1-f)*x[r,lo] + f*x[r,min(lo+1,n_in-1)]) * gain) in float64, at position
+ * i*step (the last output sits exactly on n_in-1), lo = floor, f = fraction.
+ * step = (n_in-1)/(n_out-1) (0 when n_out == 1); gain = target_sr/orig_sr when the
+ * caller asked for scaling, else 1. */
+int mia_resample_linear(const float* x, int64_t rows, int64_t n_in, int64_t n_out, double step,
+                        double gain, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -25,6 +25,7 @@ MIA_ERR_UNSUPPORTED = -2
 MIA_ERR_HIP = -3
 
 PAD_MODES = {"constant": 0, "edge": 1, "reflect": 2}
+RS_PAD_MODES = {"constant": 0, "edge": 1, "reflect": 2, "symmetric": 3, "wrap": 4}
 EPI_NONE, EPI_WHISPER, EPI_DB = 0, 1, 2
 
 
@@ -81,6 +82,10 @@ SIGNATURES = {
                          c_void_p]),
     "mia_magnitude": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "mia_phase": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
+    "mia_upfirdn": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int, c_int, c_int, c_int64,
+                            c_int64, c_int, c_void_p, c_void_p]),
+    "mia_resample_linear": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_double, c_double,
+                                    c_void_p, c_void_p]),
 }
 
 HAS_HIP_EXT: bool = False

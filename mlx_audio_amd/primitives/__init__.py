@@ -5,6 +5,7 @@ from .._lib import HAS_HIP_EXT, has_hip_extensions
 from .convert import amplitude_to_db, db_to_amplitude, db_to_power, power_to_db
 from .mel import hz_to_mel, mel_filterbank, mel_to_hz, melspectrogram
 from .mfcc import dct, mfcc
+from .resample import resample, resample_poly
 from .stft import check_nola, istft, magnitude, phase, stft
 from .windows import get_window
 
@@ -14,4 +15,5 @@ __all__ = [
     "mel_filterbank", "melspectrogram", "hz_to_mel", "mel_to_hz",
     "dct", "mfcc",
     "power_to_db", "amplitude_to_db", "db_to_power", "db_to_amplitude",
+    "resample", "resample_poly",
 ]

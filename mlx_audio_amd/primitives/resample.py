@@ -1,0 +1,210 @@
+"""Sample-rate conversion on MI355X with the signatures of
+`mlx_audio.primitives.resample` (reference python/mlx_audio/primitives/resample.py).
+
+`resample_poly` and `resample(res_type="linear")` run as HIP kernels and return,
+bit for bit, what the reference's host path (SciPy / NumPy on float32 rows) returns.
+The anti-aliasing filter of `resample_poly` is designed here on the host, once per
+(up, down), exactly as SciPy designs it (float64 windowed sinc, cast to float32).
+
+`resample(res_type="fft")` needs a real FFT of the whole signal (any length); that
+transform is not built yet, and the call says so instead of computing something else.
+"""
+
+from __future__ import annotations
+
+import functools
+import math
+
+import numpy as np
+import torch
+
+from .. import _lib
+from .._runtime import require_gpu, stream_ptr
+
+_BACKGROUND = ("mean", "median", "minimum", "maximum")
+
+
+def _validate_positive(value, name: str) -> None:
+    # primitives/_validation.py: validate_positive
+    if value <= 0:
+        raise ValueError(f"{name} must be positive, got {value}")
+
+
+def _rows(y, axis: int):
+    """Input as a contiguous float32 (rows, samples) device tensor + how to undo it."""
+    require_gpu()
+    if not isinstance(y, torch.Tensor):
+        y = torch.as_tensor(np.asarray(y))
+    if not y.is_cuda:
+        y = y.to("cuda")
+    if y.dtype != torch.float32:
+        y = y.to(torch.float32)
+    if axis != -1:
+        y = torch.movedim(y, axis, -1)
+    is_1d = y.dim() == 1
+    if is_1d:
+        y = y[None, :]
+    if y.dim() != 2:  # the reference unpacks `batch_size, orig_length = y.shape`
+        raise ValueError(f"expected a 1-D or 2-D signal, got {y.dim()}-D")
+    return y.contiguous(), is_1d
+
+
+def _restore(out: torch.Tensor, is_1d: bool, axis: int) -> torch.Tensor:
+    if is_1d:
+        out = out[0]
+    if axis != -1:
+        out = torch.movedim(out, -1, axis)
+    return out
+
+
+def resample(y, orig_sr: int, target_sr: int, res_type: str = "fft", fix: bool = True,
+             scale: bool = False, axis: int = -1) -> torch.Tensor:
+    """Resample audio to a different sample rate (reference resample.py:21-81).
+
+    res_type "linear" (resample.py:139-206) runs on the GPU; "fft" (resample.py:84-136,
+    SciPy's Fourier method over the whole signal) raises NotImplementedError.
+    """
+    _validate_positive(orig_sr, "orig_sr")
+    _validate_positive(target_sr, "target_sr")
+    if orig_sr == target_sr:
+        return y
+    if res_type == "fft":
+        raise NotImplementedError(
+            "resample(res_type='fft') needs a whole-signal real FFT of arbitrary length, which "
+            "this library does not have yet; use res_type='linear' or resample_poly(up, down).")
+    if res_type != "linear":
+        raise ValueError(f"Unknown res_type: '{res_type}'. Supported: 'fft', 'linear'")
+
+    x, is_1d = _rows(y, axis)
+    rows, n_in = x.shape
+    ratio = target_sr / orig_sr
+    n_out = int(np.round(n_in * ratio)) if fix else int(np.ceil(n_in * ratio))
+    if n_out == n_in:
+        return _restore(x, is_1d, axis)
+    if n_in == 0:
+        raise IndexError("cannot interpolate an empty signal")
+    out = torch.empty((rows, n_out), dtype=torch.float32, device=x.device)
+    # numpy.linspace(0, n_in - 1, n_out): i * ((n_in - 1) / (n_out - 1)), last point exact
+    step = (n_in - 1) / (n_out - 1) if n_out > 1 else 0.0
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().mia_resample_linear(
+            x.data_ptr(), rows, n_in, n_out, float(step), float(ratio) if scale else 1.0,
+            out.data_ptr(), stream_ptr(x.device)))
+    return _restore(out, is_1d, axis)
+
+
+@functools.lru_cache(maxsize=64)
+def _kaiser_lowpass(up: int, down: int):
+    """SciPy's default resample_poly filter for float32 input:
+    firwin(2*half_len+1, 1/max(up,down), window=('kaiser', 5.0)) in float64, cast to
+    float32, then multiplied by `up` in float32.  Returns (h, half_len)."""
+    from scipy.special import i0  # SciPy is a dependency of the reference for this function too
+
+    max_rate = max(up, down)
+    cutoff = 1.0 / max_rate
+    half_len = 10 * max_rate
+    numtaps = 2 * half_len + 1
+    m = np.arange(0, numtaps) - 0.5 * (numtaps - 1)
+    h = cutoff * np.sinc(cutoff * m)
+    n = np.arange(0, numtaps)
+    mid = (numtaps - 1) / 2.0
+    h = h * (i0(5.0 * np.sqrt(1 - ((n - mid) / mid) ** 2.0)) / i0(5.0))
+    h = h / np.sum(h)  # unit gain at DC
+    h = h.astype(np.float32)
+    h *= up
+    h.setflags(write=False)
+    return h, half_len
+
+
+def _poly_layout(n_in: int, up: int, down: int, half_len: int, n_taps: int):
+    """Zero padding in front of / behind the filter that centres the output on the input,
+    the outputs of the full convolution to drop in front, and the output length."""
+    def full_len(len_h: int) -> int:
+        nt = (n_in + (len_h + (-len_h % up)) // up - 1) * up
+        return nt // down + (1 if nt % down else 0)
+
+    n_out = -(-(n_in * up) // down)
+    pre = down - half_len % down
+    post = 0
+    skip = (half_len + pre) // down
+    while full_len(n_taps + pre + post) < n_out + skip:
+        post += 1
+    return pre, post, skip, n_out
+
+
+def _phase_table(h: np.ndarray, pre: int, post: int, up: int) -> np.ndarray:
+    """(up, taps_per_phase) float32: row t = taps t, t+up, ... of the padded filter, reversed
+    so that a row lines up with consecutive input samples, oldest first."""
+    n = pre + len(h) + post
+    full = np.zeros(n + (-n % up), np.float32)
+    full[pre:pre + len(h)] = h
+    return np.ascontiguousarray(full.reshape(-1, up).T[:, ::-1])
+
+
+_table_dev_cache: dict = {}
+
+
+def _phase_table_dev(up: int, down: int, pre: int, post: int, device) -> torch.Tensor:
+    key = (up, down, pre, post, device.index)
+    t = _table_dev_cache.get(key)
+    if t is None:
+        if len(_table_dev_cache) >= 64:
+            _table_dev_cache.clear()
+        h, _ = _kaiser_lowpass(up, down)
+        t = torch.from_numpy(_phase_table(h, pre, post, up)).to(device)
+        _table_dev_cache[key] = t
+    return t
+
+
+def resample_poly(y, up: int, down: int, axis: int = -1, padtype: str = "constant") -> torch.Tensor:
+    """Polyphase resampling by the integer ratio up/down (reference resample.py:209-302).
+
+    padtype: "constant" (zeros), "edge", "reflect", "symmetric", "wrap", or one of "mean",
+    "median", "minimum", "maximum" (that statistic of each row is subtracted before the
+    filter and added back after it).  SciPy's remaining modes ("line", "smooth",
+    "antisymmetric", "antireflect") raise NotImplementedError.
+    """
+    _validate_positive(up, "up")
+    _validate_positive(down, "down")
+    g = math.gcd(up, down)
+    up //= g
+    down //= g
+    if up == 1 and down == 1:
+        return y
+    if padtype not in _lib.RS_PAD_MODES and padtype not in _BACKGROUND:
+        if padtype in ("line", "smooth", "antisymmetric", "antireflect"):
+            raise NotImplementedError(f"padtype '{padtype}' is not built")
+        raise ValueError(
+            "padtype must be one of: maximum, mean, median, minimum, constant, wrap, edge, "
+            "smooth, symmetric, reflect, antisymmetric, antireflect, line")
+
+    x, is_1d = _rows(y, axis)
+    rows, n_in = x.shape
+    if n_in == 0:
+        raise ValueError("cannot resample an empty signal")
+    h, half_len = _kaiser_lowpass(up, down)
+    pre, post, skip, n_out = _poly_layout(n_in, up, down, half_len, len(h))
+    table = _phase_table_dev(up, down, pre, post, x.device)
+
+    background = None
+    mode = _lib.RS_PAD_MODES.get(padtype, 0)
+    if padtype in _BACKGROUND:
+        if padtype == "mean":
+            background = x.mean(dim=-1, keepdim=True)
+        elif padtype == "median":
+            srt = x.sort(dim=-1).values  # mean of the two middle samples for even lengths
+            background = ((srt[:, (n_in - 1) // 2] + srt[:, n_in // 2]) * 0.5)[:, None]
+        elif padtype == "minimum":
+            background = x.amin(dim=-1, keepdim=True)
+        else:
+            background = x.amax(dim=-1, keepdim=True)
+        x = (x - background).contiguous()
+
+    out = torch.empty((rows, n_out), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().mia_upfirdn(
+            x.data_ptr(), rows, n_in, table.data_ptr(), up, down, table.shape[1], skip, n_out,
+            mode, out.data_ptr(), stream_ptr(x.device)))
+    if background is not None:
+        out += background
+    return _restore(out, is_1d, axis)

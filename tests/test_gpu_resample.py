@@ -1,0 +1,147 @@
+"""Sample-rate conversion on the GPU against the oracle (SciPy / NumPy, the reference's
+own arithmetic for this path): bit-exact, through the C ABI."""
+
+import numpy as np
+import pytest
+import torch
+
+import oracle.resample as orc
+from mlx_audio_amd import _lib
+from mlx_audio_amd.primitives import resample, resample_poly
+
+pytestmark = pytest.mark.gpu
+
+RATIOS = [(1, 2), (2, 1), (3, 1), (1, 3), (147, 160), (160, 147), (160, 441), (441, 160),
+          (5, 7), (2, 3), (1, 6), (1, 160), (320, 441)]
+
+
+def _dev(a, gpu):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(gpu)
+
+
+@pytest.mark.parametrize("up,down", RATIOS)
+def test_resample_poly_is_bit_identical_to_scipy(gpu, up, down):
+    rng = np.random.default_rng(100 * up + down)
+    for n in (1, 2, 3, 63, 64, 1000, 4097, 30011):
+        x = rng.standard_normal((3, n)).astype(np.float32)
+        want = orc.resample_poly(x, up, down)
+        got = resample_poly(_dev(x, gpu), up, down).cpu().numpy()
+        assert got.shape == want.shape and got.dtype == np.float32
+        np.testing.assert_array_equal(got, want, err_msg=f"{up}/{down} n={n}")
+
+
+def test_resample_poly_reduces_the_ratio_and_takes_1d_and_axis(gpu):
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal(5000).astype(np.float32)
+    np.testing.assert_array_equal(resample_poly(_dev(x, gpu), 4, 8).cpu().numpy(),
+                                  orc.resample_poly(x, 1, 2))
+    x2 = rng.standard_normal((700, 3)).astype(np.float32)
+    got = resample_poly(_dev(x2, gpu), 3, 2, axis=0)
+    assert got.shape == (1050, 3)
+    np.testing.assert_array_equal(got.cpu().numpy(), orc.resample_poly(x2, 3, 2, axis=0))
+    # host arrays and other dtypes are taken too, as the reference takes anything array-like
+    np.testing.assert_array_equal(resample_poly(x.astype(np.float64), 1, 2).cpu().numpy(),
+                                  orc.resample_poly(x, 1, 2))
+
+
+@pytest.mark.parametrize("padtype", ["edge", "reflect", "symmetric", "wrap"])
+@pytest.mark.parametrize("up,down", [(1, 2), (3, 1), (160, 441), (147, 160)])
+def test_resample_poly_extension_modes(gpu, padtype, up, down):
+    rng = np.random.default_rng(11)
+    for n in (1, 2, 7, 50, 3001):   # rows far shorter than the filter wrap around many times
+        x = (rng.standard_normal((2, n)) + 3.0).astype(np.float32)
+        # SciPy divides by the reflection period 2*(n-1) = 0 for a one-sample row and the
+        # process dies with SIGFPE; here that row is extended by its only sample.
+        ref_mode = "edge" if (padtype == "reflect" and n == 1) else padtype
+        want = orc.resample_poly(x, up, down, padtype=ref_mode)
+        got = resample_poly(_dev(x, gpu), up, down, padtype=padtype).cpu().numpy()
+        np.testing.assert_array_equal(got, want, err_msg=f"{padtype} {up}/{down} n={n}")
+
+
+@pytest.mark.parametrize("padtype", ["mean", "median", "minimum", "maximum"])
+def test_resample_poly_background_modes(gpu, padtype):
+    rng = np.random.default_rng(12)
+    for n in (9, 10, 2001):
+        x = (rng.standard_normal((2, n)) + 5.0).astype(np.float32)
+        want = orc.resample_poly(x, 2, 3, padtype=padtype)
+        got = resample_poly(_dev(x, gpu), 2, 3, padtype=padtype).cpu().numpy()
+        # the row statistic is a device reduction (summation order differs for the mean)
+        tol = 0.0 if padtype in ("minimum", "maximum") else 2e-6
+        np.testing.assert_allclose(got, want, rtol=0, atol=tol)
+    with pytest.raises(NotImplementedError):
+        resample_poly(_dev(x, gpu), 2, 3, padtype="line")
+
+
+def test_resample_poly_nonfinite_samples_stay_local(gpu):
+    x = np.random.default_rng(2).standard_normal((2, 4000)).astype(np.float32)
+    x[0, 1000] = np.nan
+    x[1, 3000] = np.inf
+    want = orc.resample_poly(x, 160, 441)
+    got = resample_poly(_dev(x, gpu), 160, 441).cpu().numpy()
+    np.testing.assert_array_equal(got, want)   # NaN positions and payload-free equality
+    assert np.isfinite(got[0, :300]).all()
+
+
+@pytest.mark.parametrize("orig,target", [(44100, 16000), (16000, 44100), (48000, 16000),
+                                         (22050, 16000), (8000, 48000), (16000, 15999)])
+def test_linear_is_bit_identical_to_numpy(gpu, orig, target):
+    rng = np.random.default_rng(orig + target)
+    for n in (1, 2, 3, 101, 44100, 100003):
+        x = rng.standard_normal((2, n)).astype(np.float32)
+        for fix in (True, False):
+            for scale in (False, True):
+                want = orc.resample(x, orig, target, res_type="linear", fix=fix, scale=scale)
+                got = resample(_dev(x, gpu), orig, target, res_type="linear", fix=fix, scale=scale)
+                got = got.cpu().numpy()
+                assert got.shape == want.shape
+                np.testing.assert_array_equal(got, want, err_msg=f"n={n} fix={fix} scale={scale}")
+
+
+def test_linear_1d_axis_and_same_length(gpu):
+    rng = np.random.default_rng(8)
+    x = rng.standard_normal(1234).astype(np.float32)
+    np.testing.assert_array_equal(resample(_dev(x, gpu), 3, 2, res_type="linear").cpu().numpy(),
+                                  orc.resample(x, 3, 2, res_type="linear"))
+    x2 = rng.standard_normal((500, 2)).astype(np.float32)
+    got = resample(_dev(x2, gpu), 1, 2, res_type="linear", axis=0)
+    np.testing.assert_array_equal(got.cpu().numpy(), orc.resample(x2, 1, 2, res_type="linear", axis=0))
+    # a ratio that rounds to the same length returns the samples unchanged (resample.py:174-175)
+    same = resample(_dev(x, gpu), 100000, 100001, res_type="linear")
+    np.testing.assert_array_equal(same.cpu().numpy(), x)
+
+
+def test_full_size_clip_44k1_to_16k(gpu):
+    """30 s at 44.1 kHz -> 16 kHz (up 160, down 441), the conversion in front of the Whisper
+    front-end, on a batch; three rows are checked against SciPy, all rows against each other
+    by linearity: resample(a + 2 b) == resample(a) + 2 resample(b) up to float32 rounding."""
+    n = 44100 * 30
+    g = torch.Generator(device=gpu)
+    g.manual_seed(7)
+    x = torch.randn((16, n), generator=g, device=gpu, dtype=torch.float32)
+    y = resample_poly(x, 16000, 44100)
+    assert y.shape == (16, 480000)
+    xc = x[[0, 7, 15]].cpu().numpy()
+    np.testing.assert_array_equal(y[[0, 7, 15]].cpu().numpy(), orc.resample_poly(xc, 160, 441))
+    mix = resample_poly(x[:8] + 2.0 * x[8:], 160, 441)
+    err = (mix - (y[:8] + 2.0 * y[8:])).abs().max().item()
+    assert err < 2e-5, err
+
+
+def test_c_abi_argument_checks(gpu):
+    lib = _lib.lib()
+    x = torch.zeros(8, device=gpu)
+    out = torch.zeros(8, device=gpu)
+    tab = torch.zeros(4, device=gpu)
+    s = torch.cuda.current_stream(gpu).cuda_stream
+    assert lib.mia_upfirdn(x.data_ptr(), 1, 8, tab.data_ptr(), 0, 1, 4, 0, 8, 0,
+                           out.data_ptr(), s) == _lib.MIA_ERR_INVALID
+    assert lib.mia_upfirdn(x.data_ptr(), 1, 8, tab.data_ptr(), 1, 1, 4, 0, 8, 9,
+                           out.data_ptr(), s) == _lib.MIA_ERR_INVALID
+    assert b"padding mode" in lib.mia_last_error()
+    assert lib.mia_upfirdn(x.data_ptr(), 1, 8, tab.data_ptr(), 1, 1, 20000, 0, 8, 0,
+                           out.data_ptr(), s) == _lib.MIA_ERR_UNSUPPORTED
+    assert lib.mia_upfirdn(x.data_ptr(), 0, 8, tab.data_ptr(), 1, 1, 4, 0, 8, 0,
+                           out.data_ptr(), s) == _lib.MIA_OK    # empty batch: nothing to do
+    assert lib.mia_resample_linear(x.data_ptr(), 1, 8, 4, 5.0, 1.0, out.data_ptr(),
+                                   s) == _lib.MIA_ERR_INVALID   # would read past the row
+    assert lib.mia_resample_linear(x.data_ptr(), 1, 8, 0, 0.0, 1.0, out.data_ptr(), s) == _lib.MIA_OK
