@@ -265,8 +265,9 @@ def main() -> None:
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": measured_traffic(args.workload, clips),
                 "kernel": KERNEL_OF.get(args.workload, "fwd_kernel") + ", timed with stream "
-                          "events around each step (so the key memset and the floor pass "
-                          "launched with it are inside the measured time)",
+                          "events around each step (every launch of the step, e.g. the key "
+                          "initialisation and the floor pass of the mel workloads, is inside "
+                          "the measured time)",
                 "algorithmic_bytes_per_step": abytes,
                 "device_ms_per_step": dev_ms,
             },

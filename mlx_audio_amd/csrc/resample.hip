@@ -23,8 +23,7 @@
 
 namespace mia {
 
-constexpr int kRsWG = 256;          // threads per workgroup
-constexpr int kRsOPT = 4;           // outputs per thread
+constexpr int kRsOPT = 8;           // outputs per thread and pass, at most
 constexpr int kRsMaxSpan = 16384;   // staged input samples per workgroup, at most (64 KiB)
 constexpr int kRsMaxTable = 12288;  // phase-table entries kept in LDS, at most (48 KiB)
 
@@ -60,19 +59,21 @@ __device__ __forceinline__ float extended_sample(const float* __restrict__ x, lo
 }
 
 template <bool TABLE_IN_LDS>
-__global__ __launch_bounds__(kRsWG) void upfirdn_kernel(
+__global__ __launch_bounds__(1024) void upfirdn_kernel(
     const float* __restrict__ x, long long n_in, const float* __restrict__ table, int up, int down,
-    int P, long long skip, long long n_out, int mode, float* __restrict__ out, int run,
+    int P, long long skip, long long n_out, int mode, float* __restrict__ out, int S, int kcount,
     int span_cap, long long runs_per_row, long long total_runs, int runs_per_wg) {
-  extern __shared__ float rs_smem[];
+  extern __shared__ __attribute__((aligned(16))) float rs_smem[];
   float* xs = rs_smem;
-  float* ht = rs_smem + span_cap;
+  float* ht = rs_smem + span_cap;  // span_cap includes the slack of the 16-byte copy
   // rows of the LDS copy of the phase table have an odd pitch: lanes read different phases
   const int PL = TABLE_IN_LDS ? (P | 1) : P;
+  const int run = S * kcount;
+  const int dS = (S / up) * down;  // input samples between outputs S apart (used when up | S)
 
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, nthr = blockDim.x;
   if constexpr (TABLE_IN_LDS) {
-    for (int i = tid; i < up * P; i += kRsWG) {
+    for (int i = tid; i < up * P; i += nthr) {
       const int t = i / P;
       ht[t * PL + (i - t * P)] = table[i];
     }
@@ -81,47 +82,91 @@ __global__ __launch_bounds__(kRsWG) void upfirdn_kernel(
   const long long first = (long long)blockIdx.x * runs_per_wg;
   const long long last = first + runs_per_wg < total_runs ? first + runs_per_wg : total_runs;
   for (long long item = first; item < last; ++item) {
-  const long long row = item / runs_per_row;
-  const long long o0 = (item - row * runs_per_row) * run;
-  const long long rem = n_out - o0;
-  const int cnt = rem < run ? (int)rem : run;
-  const float* __restrict__ xr = x + row * n_in;
+    const long long row = item / runs_per_row;
+    const long long o0 = (item - row * runs_per_row) * run;
+    const long long rem = n_out - o0;
+    const int cnt = rem < run ? (int)rem : run;
+    const float* __restrict__ xr = x + row * n_in;
 
-  const long long q0 = (o0 + skip) * down;        // position of the run's first output on the
-  const long long xq0 = q0 / up;                  // upsampled grid, split into sample and phase
-  const unsigned ph0 = (unsigned)(q0 - xq0 * up);
-  const long long x_first = xq0 - P + 1;
-  const unsigned q_last = ph0 + (unsigned)(cnt - 1) * (unsigned)down;
-  const int span = (int)(q_last / (unsigned)up) + P;  // <= span_cap by the launcher's choice of run
+    const long long q0 = (o0 + skip) * down;  // position of the run's first output on the
+    const long long xq0 = q0 / up;            // upsampled grid, split into sample and phase
+    const unsigned ph0 = (unsigned)(q0 - xq0 * up);
+    const long long x_first = xq0 - P + 1;
+    const unsigned q_last = ph0 + (unsigned)(cnt - 1) * (unsigned)down;
+    const int span = (int)(q_last / (unsigned)up) + P;  // <= span_cap by the launcher's choice of run
 
-  for (int i = tid; i < span; i += kRsWG) xs[i] = extended_sample(xr, n_in, x_first + i, mode);
-  __syncthreads();
+    // Staging.  One decision per run: a span that lies inside the row is copied with
+    // independent 16-byte loads (the copy starts up to 3 samples early, on a 16-byte
+    // boundary, and `lead` remembers by how much); only runs that touch an end of the row
+    // take the per-sample path that knows about the signal extension.
+    const int lead = (int)(((uintptr_t)(xr + x_first) >> 2) & 3);
+    const int quads = (span + lead + 3) >> 2;
+    const bool inside = x_first - lead >= 0 && x_first - lead + 4LL * quads <= n_in &&
+                        (((uintptr_t)x) & 3) == 0;
+    int shift = 0;
+    if (inside) {
+      shift = lead;
+      const float4* __restrict__ src = reinterpret_cast<const float4*>(xr + x_first - lead);
+      float4* dst = reinterpret_cast<float4*>(xs);
+      int i = tid;
+      for (; i + 3 * nthr < quads; i += 4 * nthr) {
+        const float4 v0 = src[i], v1 = src[i + nthr], v2 = src[i + 2 * nthr], v3 = src[i + 3 * nthr];
+        dst[i] = v0;
+        dst[i + nthr] = v1;
+        dst[i + 2 * nthr] = v2;
+        dst[i + 3 * nthr] = v3;
+      }
+      for (; i < quads; i += nthr) dst[i] = src[i];
+    } else {
+      for (int i = tid; i < span; i += nthr) xs[i] = extended_sample(xr, n_in, x_first + i, mode);
+    }
+    __syncthreads();
 
-  const float* hk[kRsOPT];
-  const float* xk[kRsOPT];
-  float acc[kRsOPT];
+    // Thread w produces outputs w, w + S, w + 2S, ...: S is a multiple of `up`, so they
+    // share one phase and every tap is read once for all of them.
+    float* __restrict__ orow = out + row * n_out + o0;
+    for (int w = tid; w < S && w < cnt; w += nthr) {
+      const unsigned q = ph0 + (unsigned)w * (unsigned)down;
+      const unsigned xi = q / (unsigned)up;
+      const unsigned t = q - xi * (unsigned)up;
+      const float* __restrict__ hh = (TABLE_IN_LDS ? ht : table) + (size_t)t * PL;
+      const float* xk[kRsOPT];
+      float acc[kRsOPT];
 #pragma unroll
-  for (int k = 0; k < kRsOPT; ++k) {
-    int ol = tid + k * kRsWG;
-    if (ol >= cnt) ol = cnt - 1;  // duplicates a valid output; not stored
-    const unsigned q = ph0 + (unsigned)ol * (unsigned)down;
-    const unsigned xi = q / (unsigned)up;
-    const unsigned t = q - xi * (unsigned)up;
-    xk[k] = xs + xi;
-    hk[k] = (TABLE_IN_LDS ? ht : table) + (size_t)t * PL;
-    acc[k] = 0.0f;
-  }
-  for (int j = 0; j < P; ++j) {
+      for (int k = 0; k < kRsOPT; ++k) {
+        const bool live = k < kcount && w + k * S < cnt;
+        xk[k] = xs + shift + xi + (live ? k * dS : 0);  // a dead slot re-reads slot 0 and is not stored
+        acc[k] = 0.0f;
+      }
+      // taps in blocks of 8: all of a block's LDS reads are issued (at constant offsets
+      // from one address per stream) before its 64 multiply-adds, oldest sample first
+      int j = 0;
+      for (; j + 8 <= P; j += 8) {
+        float hv[8], xv[kRsOPT][8];
 #pragma unroll
-    for (int k = 0; k < kRsOPT; ++k) acc[k] = acc[k] + xk[k][j] * hk[k][j];
-  }
-  float* __restrict__ orow = out + row * n_out + o0;
+        for (int u = 0; u < 8; ++u) hv[u] = hh[j + u];
 #pragma unroll
-  for (int k = 0; k < kRsOPT; ++k) {
-    const int ol = tid + k * kRsWG;
-    if (ol < cnt) orow[ol] = acc[k];
-  }
-  __syncthreads();  // the next run overwrites the staged samples
+        for (int k = 0; k < kRsOPT; ++k) {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) xv[k][u] = xk[k][j + u];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+#pragma unroll
+          for (int k = 0; k < kRsOPT; ++k) acc[k] = acc[k] + xv[k][u] * hv[u];
+        }
+      }
+      for (; j < P; ++j) {
+        const float hv = hh[j];
+#pragma unroll
+        for (int k = 0; k < kRsOPT; ++k) acc[k] = acc[k] + xk[k][j] * hv;
+      }
+#pragma unroll
+      for (int k = 0; k < kRsOPT; ++k) {
+        if (k < kcount && w + k * S < cnt) orow[w + k * S] = acc[k];
+      }
+    }
+    __syncthreads();  // the next run overwrites the staged samples
   }
 }
 
@@ -162,25 +207,47 @@ int mia_upfirdn(const float* x, int64_t rows, int64_t n_in, const float* phase_t
   if (rows == 0 || n_out == 0) return MIA_OK;
   MIA_REQUIRE(x && phase_table && out, "null pointer");
   const int P = taps_per_phase;
-  if (P + 2 > kRsMaxSpan || (long long)up > 0x3fffffff || (long long)down > 0x3fffffff) {
+  if (P + 16 > kRsMaxSpan || (long long)up > 0x3fffffff || (long long)down > 0x3fffffff) {
     set_error("polyphase filter too long for one workgroup: %d taps per phase (limit %d)", P,
-              kRsMaxSpan - 2);
+              kRsMaxSpan - 16);
     return MIA_ERR_UNSUPPORTED;
   }
-  // Outputs per workgroup: as many as keep the staged span within its LDS budget
-  // and the positions on the upsampled grid within 32 bits.
-  long long run = kRsWG * kRsOPT;
-  const long long by_span = ((long long)(kRsMaxSpan - P - 2) * up) / down;
-  if (run > by_span) run = by_span;
+  // Outputs S apart share a filter phase when `up` divides S.  S is also the number of
+  // threads with work, so it is picked among the multiples of `up` near 256..1024 for the
+  // fewest idle lanes; a thread then produces up to kRsOPT outputs per staged span, as many
+  // as keep the span within its LDS budget and the upsampled-grid positions within 32 bits.
+  const long long by_span = ((long long)(kRsMaxSpan - P - 14) * up) / down;
   const long long by_bits = (0x7fffffffLL - up) / down;
-  if (run > by_bits) run = by_bits;
-  if (run < 1) run = 1;
-  const int span_cap = (int)(((run - 1) * down + up - 1) / up) + P + 1;
-  if (span_cap > kRsMaxSpan) {
-    set_error("down/up = %d/%d needs %d staged samples per output run (limit %d)", down, up,
-              span_cap, kRsMaxSpan);
-    return MIA_ERR_UNSUPPORTED;
+  const long long max_run = by_span < by_bits ? by_span : by_bits;
+  long long S = 0;
+  int kcount = 1, threads = 64;
+  {
+    const int target = 320;  // measured best among 320..960 for 160/441 (more workgroups per CU)
+    double best = 2.0;
+    for (long long m = 1; m * up <= 1024 || m == 1; ++m) {
+      const long long cand = m * up;
+      if (cand > max_run && S != 0) break;
+      const long long bd = cand >= 1024 ? 1024 : (cand + 63) / 64 * 64;
+      double idle = cand >= 1024 ? 0.0 : double(bd - cand) / double(bd);
+      idle += 0.002 * double(cand > target ? cand - target : target - cand) / 64.0;  // prefer ~target
+      if (idle < best) {
+        best = idle;
+        S = cand;
+        threads = (int)bd;
+      }
+    }
+    if (S > max_run) {  // not even one output per thread fits: a short run, phases not shared
+      S = max_run < 1 ? 1 : max_run;
+      threads = (int)(S >= 1024 ? 1024 : (S + 63) / 64 * 64);
+      kcount = 1;
+    } else {
+      long long k = max_run / S;
+      kcount = (int)(k > kRsOPT ? kRsOPT : k);
+      if (kcount < 1) kcount = 1;
+    }
   }
+  const long long run = S * kcount;
+  const int span_cap = ((int)(((run - 1) * down + up - 1) / up) + P + 1 + 8 + 3) & ~3;
   const bool table_lds = (long long)up * (P | 1) <= kRsMaxTable;
   const long long runs_per_row = (n_out + run - 1) / run;
   const long long total_runs = rows * runs_per_row;
@@ -195,6 +262,7 @@ int mia_upfirdn(const float* x, int64_t rows, int64_t n_in, const float* phase_t
   MIA_CHECK_HIP(hipGetDevice(&dev));
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   long long per_cu = (160 * 1024) / (long long)(lds + 256);
+  if (per_cu > 2048 / threads) per_cu = 2048 / threads;
   if (per_cu > 8) per_cu = 8;
   if (per_cu < 1) per_cu = 1;
   long long grid = (long long)cus * per_cu;
@@ -213,18 +281,18 @@ int mia_upfirdn(const float* x, int64_t rows, int64_t n_in, const float* phase_t
       MIA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kRsWG), lds, s, x, (long long)n_in,
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(threads), lds, s, x, (long long)n_in,
                        phase_table, up, down, P, (long long)skip, (long long)n_out, pad_mode, out,
-                       (int)run, span_cap, runs_per_row, total_runs, runs_per_wg);
+                       (int)S, kcount, span_cap, runs_per_row, total_runs, runs_per_wg);
   } else {
     auto kern = upfirdn_kernel<false>;
     if (lds > 64 * 1024) {
       MIA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kRsWG), lds, s, x, (long long)n_in,
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(threads), lds, s, x, (long long)n_in,
                        phase_table, up, down, P, (long long)skip, (long long)n_out, pad_mode, out,
-                       (int)run, span_cap, runs_per_row, total_runs, runs_per_wg);
+                       (int)S, kcount, span_cap, runs_per_row, total_runs, runs_per_wg);
   }
   MIA_CHECK_HIP(hipGetLastError());
   return MIA_OK;
