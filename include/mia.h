@@ -211,6 +211,24 @@ int mia_upfirdn(const float* x, int64_t rows, int64_t n_in, const float* phase_t
  * caller asked for scaling, else 1. */
 int mia_resample_linear(const float* x, int64_t rows, int64_t n_in, int64_t n_out, double step,
                         double gain, float* out, void* stream);
+/* resample(res_type="fft") (primitives/resample.py:84-136, which hands float32 rows to
+ * scipy.signal.resample at :120): rfft over the whole row of n_in samples, the spectrum
+ * truncated or zero-extended to n_out/2+1 bins (a Nyquist bin shared between the two lengths
+ * is doubled when shortening, halved when lengthening), irfft of length n_out, times
+ * n_out/n_in and `gain` (target_sr/orig_sr when the caller asked for scaling, else 1).
+ * Any n_in, n_out in [1, 2^27]: the transforms are chirp-z convolutions over power-of-two
+ * FFTs.  x: device (rows, n_in); out: device (rows, n_out).  `tables` (device,
+ * mia_resample_fft_table_bytes) is filled once per (n_in, n_out) by mia_resample_fft_tables,
+ * whose workspace needs mia_resample_fft_workspace_bytes(1, ...); `workspace` (device) must
+ * hold mia_resample_fft_workspace_bytes(rows, ...).  float32 arithmetic: agrees with SciPy's
+ * float32 result to a few 1e-6 of the row's peak (not bit-identical). */
+size_t mia_resample_fft_table_bytes(int64_t n_in, int64_t n_out);
+size_t mia_resample_fft_workspace_bytes(int64_t rows, int64_t n_in, int64_t n_out);
+int mia_resample_fft_tables(int64_t n_in, int64_t n_out, void* tables, void* workspace,
+                            size_t workspace_bytes, void* stream);
+int mia_resample_fft(const float* x, int64_t rows, int64_t n_in, int64_t n_out, float gain,
+                     const void* tables, float* out, void* workspace, size_t workspace_bytes,
+                     void* stream);
 
 #ifdef __cplusplus
 }

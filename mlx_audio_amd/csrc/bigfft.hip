@@ -1,0 +1,336 @@
+// Whole-signal Fourier resampling: rfft of a row of any length n_in, copy / truncate the
+// spectrum to n_out/2+1 bins, irfft of length n_out (what scipy.signal.resample does for real
+// input, which is what the reference's resample(res_type="fft") calls).
+//
+// A transform of arbitrary length N is taken as a chirp-z (Bluestein) convolution:
+//   DFT_N(x)[k] = conj(c[k]) * sum_n x[n] conj(c[n]) c[k-n],   c[n] = exp(i pi n^2 / N),
+// the convolution running through power-of-two FFTs of length L >= 2N-1.  Those are
+// register-resident Stockham passes over global memory: one thread owns one radix-R
+// butterfly (R = 16, or 8 / 4 / 2 for the remainder), reads its R inputs L/R apart
+// (consecutive threads read consecutive elements), multiplies by twiddles it derives from
+// one double-precision sincospi, and writes the R outputs of the autosort step; no LDS and
+// no transposes, log16(L) passes over the data.  The inverse transform is the same machine
+// applied to the conjugate spectrum.  Phases are reduced in integers (n^2 mod 2N) before
+// they become angles, so the chirps are exact to float rounding for any length.
+#include "fft_engine.h"
+#include "mia_internal.h"
+
+namespace mia {
+
+__device__ __forceinline__ float2 cmulf(float2 a, float2 b) {
+  return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x};
+}
+
+// One Stockham pass of radix R over `rows` rows of length L = 1 << log2L; Ns = product of the
+// radices of the passes before it.
+template <int R, int LOG2R>
+__global__ __launch_bounds__(256) void stockham_pass_kernel(const float2* __restrict__ in,
+                                                            float2* __restrict__ out, int log2L,
+                                                            long long rows, int Ns) {
+  const int log2Lr = log2L - LOG2R;
+  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= (rows << log2Lr)) return;
+  const long long row = g >> log2Lr;
+  const long long Lr = 1LL << log2Lr;
+  const long long j = g & (Lr - 1);
+  const float2* __restrict__ src = in + (row << log2L) + j;
+  float2 v[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) v[r] = src[(long long)r * Lr];
+  const long long m = j & (long long)(Ns - 1);
+  if (Ns > 1) {
+    double s1, c1;
+    sincospi(-2.0 * (double)m / ((double)Ns * (double)R), &s1, &c1);
+    double wr = c1, wi = s1;
+#pragma unroll
+    for (int r = 1; r < R; ++r) {
+      v[r] = cmulf(v[r], float2{(float)wr, (float)wi});
+      const double nr = wr * c1 - wi * s1;
+      wi = wr * s1 + wi * c1;
+      wr = nr;
+    }
+  }
+  Dft<R>::run(v);
+  float2* __restrict__ dst = out + (row << log2L) + (j - m) * R + m;
+#pragma unroll
+  for (int k = 0; k < R; ++k) dst[(long long)k * Ns] = v[k];
+}
+
+// c[n] = exp(i pi n^2 / N), n < N.
+__global__ void chirp_kernel(long long N, float2* __restrict__ c) {
+  const long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const long long q = (n * n) % (2 * N);
+  double s, co;
+  sincospi((double)q / (double)N, &s, &co);
+  c[n] = {(float)co, (float)s};
+}
+
+// The convolution kernel of length L: b[m] = b[L-m] = c[m] for m < N, zero between.
+__global__ void chirp_filter_kernel(const float2* __restrict__ c, long long N, long long L,
+                                    float2* __restrict__ b) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= L) return;
+  float2 v = {0.0f, 0.0f};
+  if (i < N) v = c[i];
+  else if (L - i < N) v = c[L - i];
+  b[i] = v;
+}
+
+// a[row, n] = x[row, n] * conj(c[n]) for n < N, zero up to L.
+__global__ void chirp_in_real_kernel(const float* __restrict__ x, const float2* __restrict__ c,
+                                     long long N, int log2L, long long rows,
+                                     float2* __restrict__ a) {
+  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= (rows << log2L)) return;
+  const long long row = g >> log2L, n = g & ((1LL << log2L) - 1);
+  float2 v = {0.0f, 0.0f};
+  if (n < N) {
+    const float xv = x[row * N + n];
+    const float2 cn = c[n];
+    v = {xv * cn.x, -xv * cn.y};
+  }
+  a[g] = v;
+}
+
+// a[row, i] = conj(a[row, i] * B[i]): the spectrum product, conjugated so that a forward
+// transform of it yields the conjugate of the (unnormalised) inverse transform.
+__global__ void spectrum_product_kernel(float2* __restrict__ a, const float2* __restrict__ B,
+                                        int log2L, long long rows) {
+  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= (rows << log2L)) return;
+  const float2 p = cmulf(a[g], B[g & ((1LL << log2L) - 1)]);
+  a[g] = {p.x, -p.y};
+}
+
+// From the first convolution to the input of the second.  r1[row, k] holds the conjugate of
+// L1 * (convolution), so X[k] = conj(cN[k] * r1[k]) / L1 is bin k of the length-N transform.
+// The output spectrum keeps bins below nyq, scales the shared Nyquist bin, is extended to all
+// M bins by Hermitian symmetry (imaginary parts of DC and of an even M's Nyquist bin are
+// dropped, as a complex-to-real transform ignores them), conjugated (inverse transform as a
+// forward one) and multiplied by conj(cM[k]): the chirp-premultiplied input of the second
+// convolution, zero up to L2.
+__global__ void resize_spectrum_kernel(const float2* __restrict__ r1, const float2* __restrict__ cN,
+                                       const float2* __restrict__ cM, long long N, long long M,
+                                       int log2L1, int log2L2, long long rows, long long nyq,
+                                       long long shared_bin, float shared_scale, float inv_L1,
+                                       float2* __restrict__ a2) {
+  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= (rows << log2L2)) return;
+  const long long row = g >> log2L2, k = g & ((1LL << log2L2) - 1);
+  float2 v = {0.0f, 0.0f};
+  if (k < M) {
+    const bool neg = 2 * k > M;
+    const long long kk = neg ? M - k : k;
+    if (kk < nyq) {
+      const float2 p = cmulf(cN[kk], r1[(row << log2L1) + kk]);
+      float2 X = {p.x * inv_L1, -p.y * inv_L1};
+      if (kk == shared_bin) X = {X.x * shared_scale, X.y * shared_scale};
+      if (kk == 0 || 2 * kk == M) X.y = 0.0f;
+      // Yfull = neg ? conj(X) : X;  Z = conj(Yfull)
+      const float2 Z = {X.x, neg ? X.y : -X.y};
+      const float2 cm = cM[k];
+      v = cmulf(Z, float2{cm.x, -cm.y});
+    }
+  }
+  a2[g] = v;
+}
+
+// y[row, n] = Re(cM[n] * r2[row, n]) * scale, n < M.
+__global__ void chirp_out_real_kernel(const float2* __restrict__ r2, const float2* __restrict__ cM,
+                                      long long M, int log2L2, long long rows, float scale,
+                                      float* __restrict__ y) {
+  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= rows * M) return;
+  const long long row = g / M, n = g - row * M;
+  const float2 r = r2[(row << log2L2) + n];
+  const float2 cm = cM[n];
+  y[g] = (cm.x * r.x - cm.y * r.y) * scale;
+}
+
+static int ceil_log2(long long v) {
+  int p = 0;
+  while ((1LL << p) < v) ++p;
+  return p;
+}
+static int conv_log2(long long N) {  // log2 of the convolution length for a length-N transform
+  const int p = ceil_log2(2 * N - 1);
+  return p < 1 ? 1 : p;
+}
+
+static inline unsigned blocks_for(long long n) { return (unsigned)((n + 255) / 256); }
+
+// Forward FFT of `rows` rows of length 1 << log2L held in `a`; `b` is scratch of the same
+// size.  Returns (through *result) which of the two buffers holds the transform.
+static int fft_pow2(float2* a, float2* b, int log2L, long long rows, hipStream_t s,
+                    float2** result) {
+  if ((rows << log2L) / 2 >= (1LL << 31) * 256) {
+    set_error("resample: %lld rows of 2^%d points do not fit one launch", rows, log2L);
+    return MIA_ERR_UNSUPPORTED;
+  }
+  int left = log2L, Ns = 1;
+  float2 *src = a, *dst = b;
+  while (left > 0) {
+    int lg = left >= 4 ? 4 : left;
+    if (left == 5) lg = 3;  // 8 * 4 rather than 16 * 2
+    const long long threads = rows << (log2L - lg);
+    const unsigned grid = blocks_for(threads);
+    switch (lg) {
+      case 4: hipLaunchKernelGGL((stockham_pass_kernel<16, 4>), dim3(grid), dim3(256), 0, s, src, dst, log2L, rows, Ns); break;
+      case 3: hipLaunchKernelGGL((stockham_pass_kernel<8, 3>), dim3(grid), dim3(256), 0, s, src, dst, log2L, rows, Ns); break;
+      case 2: hipLaunchKernelGGL((stockham_pass_kernel<4, 2>), dim3(grid), dim3(256), 0, s, src, dst, log2L, rows, Ns); break;
+      default: hipLaunchKernelGGL((stockham_pass_kernel<2, 1>), dim3(grid), dim3(256), 0, s, src, dst, log2L, rows, Ns); break;
+    }
+    MIA_CHECK_HIP(hipGetLastError());
+    Ns <<= lg;
+    left -= lg;
+    float2* t = src;
+    src = dst;
+    dst = t;
+  }
+  *result = src;
+  return MIA_OK;
+}
+
+struct RfLayout {
+  long long N, M;
+  int p1, p2;
+  long long L1, L2, Lmax;
+  size_t off_cN, off_cM, off_B1, off_B2, table_elems;
+};
+static RfLayout rf_layout(long long n_in, long long n_out) {
+  RfLayout l;
+  l.N = n_in;
+  l.M = n_out;
+  l.p1 = conv_log2(n_in);
+  l.p2 = conv_log2(n_out);
+  l.L1 = 1LL << l.p1;
+  l.L2 = 1LL << l.p2;
+  l.Lmax = l.L1 > l.L2 ? l.L1 : l.L2;
+  l.off_cN = 0;
+  l.off_cM = (size_t)n_in;
+  l.off_B1 = l.off_cM + (size_t)n_out;
+  l.off_B2 = l.off_B1 + (size_t)l.L1;
+  l.table_elems = l.off_B2 + (size_t)l.L2;
+  return l;
+}
+
+}  // namespace mia
+
+extern "C" {
+
+size_t mia_resample_fft_table_bytes(int64_t n_in, int64_t n_out) {
+  if (n_in < 1 || n_out < 1 || n_in > (1LL << 27) || n_out > (1LL << 27)) return 0;
+  return mia::rf_layout(n_in, n_out).table_elems * sizeof(float2);
+}
+
+size_t mia_resample_fft_workspace_bytes(int64_t rows, int64_t n_in, int64_t n_out) {
+  if (rows < 1 || n_in < 1 || n_out < 1 || n_in > (1LL << 27) || n_out > (1LL << 27)) return 0;
+  return 2 * (size_t)rows * (size_t)mia::rf_layout(n_in, n_out).Lmax * sizeof(float2);
+}
+
+int mia_resample_fft_tables(int64_t n_in, int64_t n_out, void* tables, void* workspace,
+                            size_t workspace_bytes, void* stream) {
+  using namespace mia;
+  MIA_REQUIRE(n_in >= 1 && n_out >= 1, "n_in and n_out must be >= 1");
+  if (n_in > (1LL << 27) || n_out > (1LL << 27)) {
+    set_error("resample: rows longer than 2^27 samples are not supported");
+    return MIA_ERR_UNSUPPORTED;
+  }
+  MIA_REQUIRE(tables && workspace, "null pointer");
+  const RfLayout l = rf_layout(n_in, n_out);
+  MIA_REQUIRE(workspace_bytes >= 2 * (size_t)l.Lmax * sizeof(float2),
+              "workspace too small: %zu bytes, need %zu", workspace_bytes,
+              2 * (size_t)l.Lmax * sizeof(float2));
+  hipStream_t s = (hipStream_t)stream;
+  float2* T = (float2*)tables;
+  float2* w0 = (float2*)workspace;
+  float2* w1 = w0 + l.Lmax;
+  hipLaunchKernelGGL(chirp_kernel, dim3(blocks_for(l.N)), dim3(256), 0, s, l.N, T + l.off_cN);
+  hipLaunchKernelGGL(chirp_kernel, dim3(blocks_for(l.M)), dim3(256), 0, s, l.M, T + l.off_cM);
+  MIA_CHECK_HIP(hipGetLastError());
+  const long long NN[2] = {l.N, l.M}, LL[2] = {l.L1, l.L2};
+  const int PP[2] = {l.p1, l.p2};
+  const size_t offc[2] = {l.off_cN, l.off_cM}, offB[2] = {l.off_B1, l.off_B2};
+  for (int i = 0; i < 2; ++i) {
+    hipLaunchKernelGGL(chirp_filter_kernel, dim3(blocks_for(LL[i])), dim3(256), 0, s, T + offc[i],
+                       NN[i], LL[i], w0);
+    MIA_CHECK_HIP(hipGetLastError());
+    float2* res = nullptr;
+    const int rc = fft_pow2(w0, w1, PP[i], 1, s, &res);
+    if (rc != MIA_OK) return rc;
+    MIA_CHECK_HIP(hipMemcpyAsync(T + offB[i], res, (size_t)LL[i] * sizeof(float2),
+                                 hipMemcpyDeviceToDevice, s));
+  }
+  return MIA_OK;
+}
+
+int mia_resample_fft(const float* x, int64_t rows, int64_t n_in, int64_t n_out, float gain,
+                     const void* tables, float* out, void* workspace, size_t workspace_bytes,
+                     void* stream) {
+  using namespace mia;
+  MIA_REQUIRE(rows >= 0 && n_in >= 1 && n_out >= 1, "rows, n_in, n_out must be >= 0, 1, 1");
+  if (n_in > (1LL << 27) || n_out > (1LL << 27)) {
+    set_error("resample: rows longer than 2^27 samples are not supported");
+    return MIA_ERR_UNSUPPORTED;
+  }
+  if (rows == 0) return MIA_OK;
+  MIA_REQUIRE(x && tables && out && workspace, "null pointer");
+  const RfLayout l = rf_layout(n_in, n_out);
+  const size_t need = 2 * (size_t)rows * (size_t)l.Lmax * sizeof(float2);
+  MIA_REQUIRE(workspace_bytes >= need, "workspace too small: %zu bytes, need %zu", workspace_bytes,
+              need);
+  if ((rows << (l.p1 > l.p2 ? l.p1 : l.p2)) >= (1LL << 31) * 256) {
+    set_error("resample: %lld rows of %lld points do not fit one launch (split the batch)",
+              (long long)rows, (long long)l.Lmax);
+    return MIA_ERR_UNSUPPORTED;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const float2* T = (const float2*)tables;
+  float2* w0 = (float2*)workspace;
+  float2* w1 = w0 + (size_t)rows * l.Lmax;
+
+  // length-N transform of every row
+  hipLaunchKernelGGL(chirp_in_real_kernel, dim3(blocks_for(rows << l.p1)), dim3(256), 0, s, x,
+                     T + l.off_cN, l.N, l.p1, (long long)rows, w0);
+  MIA_CHECK_HIP(hipGetLastError());
+  float2 *A = nullptr, *R1 = nullptr, *A2 = nullptr, *R2 = nullptr;
+  int rc = fft_pow2(w0, w1, l.p1, rows, s, &A);
+  if (rc != MIA_OK) return rc;
+  hipLaunchKernelGGL(spectrum_product_kernel, dim3(blocks_for(rows << l.p1)), dim3(256), 0, s, A,
+                     T + l.off_B1, l.p1, (long long)rows);
+  MIA_CHECK_HIP(hipGetLastError());
+  rc = fft_pow2(A, A == w0 ? w1 : w0, l.p1, rows, s, &R1);
+  if (rc != MIA_OK) return rc;
+
+  // spectrum of the output, then the length-M inverse transform
+  const long long Nmin = l.N < l.M ? l.N : l.M;
+  const long long nyq = Nmin / 2 + 1;
+  long long shared_bin = -1;
+  float shared_scale = 1.0f;
+  if (Nmin % 2 == 0 && l.N != l.M) {
+    shared_bin = Nmin / 2;
+    shared_scale = l.M < l.N ? 2.0f : 0.5f;
+  }
+  A2 = R1 == w0 ? w1 : w0;
+  hipLaunchKernelGGL(resize_spectrum_kernel, dim3(blocks_for(rows << l.p2)), dim3(256), 0, s, R1,
+                     T + l.off_cN, T + l.off_cM, l.N, l.M, l.p1, l.p2, (long long)rows, nyq,
+                     shared_bin, shared_scale, (float)(1.0 / (double)l.L1), A2);
+  MIA_CHECK_HIP(hipGetLastError());
+  float2* other = A2 == w0 ? w1 : w0;
+  float2* A2f = nullptr;
+  rc = fft_pow2(A2, other, l.p2, rows, s, &A2f);
+  if (rc != MIA_OK) return rc;
+  hipLaunchKernelGGL(spectrum_product_kernel, dim3(blocks_for(rows << l.p2)), dim3(256), 0, s, A2f,
+                     T + l.off_B2, l.p2, (long long)rows);
+  MIA_CHECK_HIP(hipGetLastError());
+  rc = fft_pow2(A2f, A2f == w0 ? w1 : w0, l.p2, rows, s, &R2);
+  if (rc != MIA_OK) return rc;
+  const float scale = (float)((double)gain / ((double)l.L2 * (double)l.N));
+  hipLaunchKernelGGL(chirp_out_real_kernel, dim3(blocks_for(rows * l.M)), dim3(256), 0, s, R2,
+                     T + l.off_cM, l.M, l.p2, (long long)rows, scale, out);
+  MIA_CHECK_HIP(hipGetLastError());
+  return MIA_OK;
+}
+
+}  // extern "C"

@@ -6,8 +6,9 @@ bit for bit, what the reference's host path (SciPy / NumPy on float32 rows) retu
 The anti-aliasing filter of `resample_poly` is designed here on the host, once per
 (up, down), exactly as SciPy designs it (float64 windowed sinc, cast to float32).
 
-`resample(res_type="fft")` needs a real FFT of the whole signal (any length); that
-transform is not built yet, and the call says so instead of computing something else.
+`resample(res_type="fft")`, the default, transforms the whole row (any length) on the GPU
+as chirp-z convolutions over power-of-two FFTs; it agrees with SciPy's float32 result to
+float32 FFT round-off (a few 1e-6 of the row's peak), not bit for bit.
 """
 
 from __future__ import annotations
@@ -61,18 +62,14 @@ def resample(y, orig_sr: int, target_sr: int, res_type: str = "fft", fix: bool =
              scale: bool = False, axis: int = -1) -> torch.Tensor:
     """Resample audio to a different sample rate (reference resample.py:21-81).
 
-    res_type "linear" (resample.py:139-206) runs on the GPU; "fft" (resample.py:84-136,
-    SciPy's Fourier method over the whole signal) raises NotImplementedError.
+    Both methods run on the GPU: "fft" (resample.py:84-136, SciPy's Fourier method over the
+    whole signal) and "linear" (resample.py:139-206).
     """
     _validate_positive(orig_sr, "orig_sr")
     _validate_positive(target_sr, "target_sr")
     if orig_sr == target_sr:
         return y
-    if res_type == "fft":
-        raise NotImplementedError(
-            "resample(res_type='fft') needs a whole-signal real FFT of arbitrary length, which "
-            "this library does not have yet; use res_type='linear' or resample_poly(up, down).")
-    if res_type != "linear":
+    if res_type not in ("fft", "linear"):
         raise ValueError(f"Unknown res_type: '{res_type}'. Supported: 'fft', 'linear'")
 
     x, is_1d = _rows(y, axis)
@@ -82,7 +79,11 @@ def resample(y, orig_sr: int, target_sr: int, res_type: str = "fft", fix: bool =
     if n_out == n_in:
         return _restore(x, is_1d, axis)
     if n_in == 0:
-        raise IndexError("cannot interpolate an empty signal")
+        raise IndexError("cannot resample an empty signal")
+    if res_type == "fft":
+        if n_out < 1:  # scipy.signal.resample cannot produce an empty row either
+            raise ValueError(f"resampling {n_in} samples by {ratio} leaves no output samples")
+        return _restore(_resample_fft(x, n_out, float(ratio) if scale else 1.0), is_1d, axis)
     out = torch.empty((rows, n_out), dtype=torch.float32, device=x.device)
     # numpy.linspace(0, n_in - 1, n_out): i * ((n_in - 1) / (n_out - 1)), last point exact
     step = (n_in - 1) / (n_out - 1) if n_out > 1 else 0.0
@@ -91,6 +92,42 @@ def resample(y, orig_sr: int, target_sr: int, res_type: str = "fft", fix: bool =
             x.data_ptr(), rows, n_in, n_out, float(step), float(ratio) if scale else 1.0,
             out.data_ptr(), stream_ptr(x.device)))
     return _restore(out, is_1d, axis)
+
+
+_FFT_WORKSPACE_BYTES = 2 << 30  # rows are processed in chunks that keep the workspace below this
+_fft_tables_cache: dict = {}
+
+
+def _resample_fft(x: torch.Tensor, n_out: int, gain: float) -> torch.Tensor:
+    """scipy.signal.resample(x, n_out, axis=-1) * gain for float32 rows (resample.py:117-126)."""
+    lib = _lib.lib()
+    rows, n_in = x.shape
+    dev = x.device
+    per_row = lib.mia_resample_fft_workspace_bytes(1, n_in, n_out)
+    if per_row == 0:
+        raise NotImplementedError(
+            f"resample(res_type='fft'): rows of {n_in} -> {n_out} samples exceed the supported 2^27")
+    chunk = max(1, min(rows, _FFT_WORKSPACE_BYTES // per_row))
+    out = torch.empty((rows, n_out), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        stream = stream_ptr(dev)
+        work = torch.empty(chunk * per_row, dtype=torch.uint8, device=dev)
+        key = (n_in, n_out, dev.index)
+        tables = _fft_tables_cache.get(key)
+        if tables is None:
+            if len(_fft_tables_cache) >= 8:
+                _fft_tables_cache.clear()
+            tables = torch.empty(lib.mia_resample_fft_table_bytes(n_in, n_out), dtype=torch.uint8,
+                                 device=dev)
+            _lib.check(lib.mia_resample_fft_tables(n_in, n_out, tables.data_ptr(), work.data_ptr(),
+                                                   work.numel(), stream))
+            _fft_tables_cache[key] = tables
+        for r0 in range(0, rows, chunk):
+            n = min(chunk, rows - r0)
+            _lib.check(lib.mia_resample_fft(x[r0:r0 + n].data_ptr(), n, n_in, n_out, gain,
+                                            tables.data_ptr(), out[r0:r0 + n].data_ptr(),
+                                            work.data_ptr(), work.numel(), stream))
+    return out
 
 
 @functools.lru_cache(maxsize=64)

@@ -127,6 +127,125 @@ def test_full_size_clip_44k1_to_16k(gpu):
     assert err < 2e-5, err
 
 
+FFT_TOL = 2e-6  # of the row's peak: float32 FFT round-off (SciPy's own float32 path: <= 7e-7)
+
+FFT_SIZES = [(1, 3), (2, 3), (3, 2), (2, 1), (7, 5), (16, 8), (8, 16), (17, 16), (441, 160),
+             (160, 441), (1000, 999), (1001, 1000), (4410, 1600), (44100, 16000),
+             (100003, 36283), (65536, 32768), (32768, 65536)]
+
+
+@pytest.mark.parametrize("n,m", FFT_SIZES)
+def test_fourier_method_matches_scipy(gpu, n, m):
+    """Any pair of lengths (primes included); checked against SciPy in float64 and float32."""
+    import scipy.signal as ss
+
+    rng = np.random.default_rng(n * 7 + m)
+    x = rng.standard_normal((3, n)).astype(np.float32)
+    got = resample(_dev(x, gpu), n, m, res_type="fft").cpu().numpy()
+    want = orc.resample(x, n, m, res_type="fft")
+    truth = ss.resample(x.astype(np.float64), m, axis=-1)
+    assert got.shape == want.shape and got.dtype == np.float32
+    peak = np.abs(truth).max()
+    assert np.abs(got - truth).max() <= FFT_TOL * peak
+    assert np.abs(got - want).max() <= FFT_TOL * peak
+
+
+def test_fourier_method_options_and_shapes(gpu):
+    rng = np.random.default_rng(77)
+    x = rng.standard_normal((2, 4409)).astype(np.float32)
+    for fix in (True, False):
+        for scale in (False, True):
+            want = orc.resample(x, 44100, 16000, fix=fix, scale=scale)
+            got = resample(_dev(x, gpu), 44100, 16000, fix=fix, scale=scale).cpu().numpy()  # default = fft
+            assert got.shape == want.shape
+            assert np.abs(got - want).max() <= FFT_TOL * np.abs(want).max()
+    one = resample(_dev(x[0], gpu), 44100, 48000)
+    assert one.shape == orc.resample(x[0], 44100, 48000).shape
+    assert np.abs(one.cpu().numpy() - orc.resample(x[0], 44100, 48000)).max() <= FFT_TOL * 5
+    xt = np.ascontiguousarray(x.T)
+    got = resample(_dev(xt, gpu), 2, 1, axis=0)
+    want = orc.resample(xt, 2, 1, axis=0)
+    assert got.shape == want.shape == (2204, 2)   # numpy.round(2204.5) = 2204
+    assert np.abs(got.cpu().numpy() - want).max() <= FFT_TOL * 5
+    with pytest.raises(ValueError, match="no output samples"):
+        resample(_dev(x[:, :1], gpu), 48000, 8000)
+
+
+def test_fourier_method_known_answers(gpu):
+    # a constant stays that constant; a sine on a bin of both grids keeps amplitude and frequency
+    c = np.full((1, 3000), 0.75, np.float32)
+    got = resample(_dev(c, gpu), 3000, 1234).cpu().numpy()
+    np.testing.assert_allclose(got, 0.75, rtol=0, atol=2e-6)
+    n, m, cycles = 44100, 16000, 440
+    t = np.arange(n) / n
+    x = np.sin(2 * np.pi * cycles * t).astype(np.float32)[None]
+    got = resample(_dev(x, gpu), n, m).cpu().numpy()[0]
+    want = np.sin(2 * np.pi * cycles * np.arange(m) / m)
+    np.testing.assert_allclose(got, want, rtol=0, atol=5e-6)
+    # content above the new Nyquist frequency is removed, not aliased
+    hi = np.sin(2 * np.pi * 12000 * t).astype(np.float32)[None]
+    assert np.abs(resample(_dev(hi, gpu), n, m).cpu().numpy()).max() < 1e-5
+
+
+def test_fourier_method_row_chunks_are_independent(gpu, monkeypatch):
+    import importlib
+
+    mod = importlib.import_module("mlx_audio_amd.primitives.resample")
+    rng = np.random.default_rng(9)
+    x = _dev(rng.standard_normal((5, 30000)).astype(np.float32), gpu)
+    whole = resample(x, 30000, 10007)
+    per_row = _lib.lib().mia_resample_fft_workspace_bytes(1, 30000, 10007)
+    monkeypatch.setattr(mod, "_FFT_WORKSPACE_BYTES", 2 * per_row)   # forces chunks of 2 rows
+    chunked = resample(x, 30000, 10007)
+    assert torch.equal(whole, chunked)
+    assert torch.equal(resample(x[3], 30000, 10007), whole[3])       # batch invariance, bit for bit
+
+
+def test_full_size_clip_fourier_44k1_to_16k(gpu):
+    """30 s at 44.1 kHz -> 16 kHz by the Fourier method (the conversion the reference's
+    front doors make before the Whisper front-end): two rows against SciPy, eight rows
+    through linearity."""
+    import scipy.signal as ss
+
+    n, m = 44100 * 30, 16000 * 30
+    g = torch.Generator(device=gpu)
+    g.manual_seed(11)
+    x = torch.randn((8, n), generator=g, device=gpu, dtype=torch.float32)
+    y = resample(x, 44100, 16000)
+    assert y.shape == (8, m)
+    xc = x[[0, 7]].cpu().numpy()
+    truth = ss.resample(xc.astype(np.float64), m, axis=-1)
+    assert np.abs(y[[0, 7]].cpu().numpy() - truth).max() <= FFT_TOL * np.abs(truth).max()
+    mix = resample(x[:4] + 2.0 * x[4:], 44100, 16000)
+    assert (mix - (y[:4] + 2.0 * y[4:])).abs().max().item() < 2e-5
+
+
+def test_resample_golden_vectors(gpu):
+    import os
+
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "resample_golden.npz"))
+    x = _dev(gold["x"], gpu)
+    for key in gold.files:
+        if key == "x":
+            continue
+        kind, *args = key.split("_")
+        if kind == "poly":
+            pad = args[2] if len(args) > 2 else "constant"
+            got = resample_poly(x, int(args[0]), int(args[1]), padtype=pad).cpu().numpy()
+            np.testing.assert_array_equal(got, gold[key], err_msg=key)
+        elif kind == "linear":
+            got = resample(x, int(args[0]), int(args[1]), res_type="linear").cpu().numpy()
+            np.testing.assert_array_equal(got, gold[key], err_msg=key)
+        else:
+            if len(args) > 2:
+                got = resample(x[:, :4409], int(args[0]), int(args[1]), fix=False, scale=True)
+            else:
+                got = resample(x, int(args[0]), int(args[1]))
+            got = got.cpu().numpy()
+            assert got.shape == gold[key].shape, key
+            assert np.abs(got - gold[key]).max() <= FFT_TOL * np.abs(gold[key]).max(), key
+
+
 def test_c_abi_argument_checks(gpu):
     lib = _lib.lib()
     x = torch.zeros(8, device=gpu)
@@ -145,3 +264,17 @@ def test_c_abi_argument_checks(gpu):
     assert lib.mia_resample_linear(x.data_ptr(), 1, 8, 4, 5.0, 1.0, out.data_ptr(),
                                    s) == _lib.MIA_ERR_INVALID   # would read past the row
     assert lib.mia_resample_linear(x.data_ptr(), 1, 8, 0, 0.0, 1.0, out.data_ptr(), s) == _lib.MIA_OK
+    # Fourier method: sizes, workspace
+    assert lib.mia_resample_fft_table_bytes(8, 4) == 8 * (8 + 4 + 16 + 8)
+    assert lib.mia_resample_fft_workspace_bytes(3, 8, 4) == 2 * 3 * 16 * 8
+    assert lib.mia_resample_fft_table_bytes(1 << 28, 4) == 0
+    tab8 = torch.zeros(lib.mia_resample_fft_table_bytes(8, 4), dtype=torch.uint8, device=gpu)
+    work = torch.zeros(lib.mia_resample_fft_workspace_bytes(1, 8, 4), dtype=torch.uint8, device=gpu)
+    assert lib.mia_resample_fft_tables(8, 4, tab8.data_ptr(), work.data_ptr(), work.numel(), s) == _lib.MIA_OK
+    assert lib.mia_resample_fft(x.data_ptr(), 1, 8, 4, 1.0, tab8.data_ptr(), out.data_ptr(),
+                                work.data_ptr(), work.numel() - 1, s) == _lib.MIA_ERR_INVALID
+    assert b"workspace too small" in lib.mia_last_error()
+    assert lib.mia_resample_fft(x.data_ptr(), 1, 8, 4, 1.0, tab8.data_ptr(), out.data_ptr(),
+                                work.data_ptr(), work.numel(), s) == _lib.MIA_OK
+    assert lib.mia_resample_fft(x.data_ptr(), 1, 0, 4, 1.0, tab8.data_ptr(), out.data_ptr(),
+                                work.data_ptr(), work.numel(), s) == _lib.MIA_ERR_INVALID
