@@ -13,6 +13,7 @@ Workloads (config.workload):
   mfcc40      1024 x 30 s @16 kHz, n_fft 2048 / hop 512 / 128 mels -> 40 MFCC
   htdemucs    16 stereo x 60 s @44.1 kHz STFT+iSTFT round trip, n_fft 4096 / hop 1024
   resample    512 x 30 s @44.1 kHz -> 16 kHz, polyphase (up 160 / down 441)
+  resample_fft 64 x 30 s @44.1 kHz -> 16 kHz, Fourier method (the reference's default)
 """
 
 from __future__ import annotations
@@ -35,7 +36,7 @@ def make_workload(name: str, clips: int, device, seed: int):
     import torch
 
     from mlx_audio_amd.frontends import clap_log_mel, compute_log_mel_spectrogram
-    from mlx_audio_amd.primitives import istft, mfcc, resample_poly, stft
+    from mlx_audio_amd.primitives import istft, mfcc, resample, resample_poly, stft
 
     gen = torch.Generator(device=device)
     gen.manual_seed(seed)
@@ -85,6 +86,13 @@ def make_workload(name: str, clips: int, device, seed: int):
         return (lambda: resample_poly(y, 16000, 44100), clips * 30.0 / 3600.0, abytes,
                 f"polyphase resampling 44.1 kHz -> 16 kHz (up 160, down 441, 56 taps per "
                 f"output), {clips} x 30 s clips", "resample_poly audio-hours/sec (44.1k -> 16k)")
+    if name == "resample_fft":
+        T = 44100 * 30
+        y = torch.randn((clips, T), generator=gen, device=device, dtype=torch.float32)
+        abytes = clips * (T * 4 + 480000 * 4)
+        return (lambda: resample(y, 44100, 16000), clips * 30.0 / 3600.0, abytes,
+                f"Fourier-method resampling 44.1 kHz -> 16 kHz (rfft 1 323 000 -> irfft 480 000 "
+                f"per clip), {clips} x 30 s clips", "resample(fft) audio-hours/sec (44.1k -> 16k)")
     raise SystemExit(f"unknown workload {name}")
 
 
@@ -94,6 +102,8 @@ KERNEL_OF = {
     "mfcc40": "fwd_kernel<2048, mel> (fused rFFT+mel+dB) followed by dct2_mfma_kernel",
     "htdemucs": "fwd_kernel<4096> then istft_kernel<4096> (fused inverse FFT + overlap-add)",
     "resample": "upfirdn_kernel (polyphase FIR, input span and phase table staged in LDS)",
+    "resample_fft": "stockham_pass_kernel<16> x 22 + chirp / spectrum kernels (two chirp-z "
+                    "convolutions per clip)",
 }
 
 
@@ -189,7 +199,7 @@ def main() -> None:
               "torch.distributed.run for N>1", file=sys.stderr)
 
     default_clips = {"whisper128": 1024, "clap64": 1024, "mfcc40": 1024, "htdemucs": 32,
-                     "resample": 512}
+                     "resample": 512, "resample_fft": 64}
     clips = args.clips or default_clips.get(args.workload, 1024)
     step, units, abytes, desc, metric = make_workload(args.workload, clips, device, 1234 + rank)
 

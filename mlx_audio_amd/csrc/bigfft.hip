@@ -148,6 +148,164 @@ __global__ void chirp_out_real_kernel(const float2* __restrict__ r2, const float
   y[g] = (cm.x * r.x - cm.y * r.y) * scale;
 }
 
+// ---------------------------------------------------------------------------
+// Direct path for even lengths whose halves factor into 2, 3, 5 and 7: the row, read as
+// N/2 complex numbers z[n] = x[2n] + i x[2n+1], goes through Stockham passes of mixed radix
+// and the real-input split is folded into the kernel that resizes the spectrum.
+// ---------------------------------------------------------------------------
+template <int R>
+__global__ __launch_bounds__(256) void stockham_any_kernel(const float2* __restrict__ in,
+                                                           float2* __restrict__ out, unsigned L,
+                                                           unsigned Ns, long long rows) {
+  const unsigned Lr = L / R;
+  const unsigned j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= Lr) return;
+  const unsigned m = j % Ns;
+  double s1 = 0.0, c1 = 1.0;
+  if (Ns > 1) sincospi(-2.0 * (double)m / ((double)Ns * (double)R), &s1, &c1);
+  float2 w[R];
+  {
+    double wr = c1, wi = s1;
+#pragma unroll
+    for (int r = 1; r < R; ++r) {
+      w[r] = {(float)wr, (float)wi};
+      const double nr = wr * c1 - wi * s1;
+      wi = wr * s1 + wi * c1;
+      wr = nr;
+    }
+  }
+  const size_t base = (size_t)(j - m) * R + m;
+  for (long long row = blockIdx.y; row < rows; row += gridDim.y) {
+    const float2* __restrict__ src = in + (size_t)row * L + j;
+    float2 v[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) v[r] = src[(size_t)r * Lr];
+    if (Ns > 1) {
+#pragma unroll
+      for (int r = 1; r < R; ++r) v[r] = cmulf(v[r], w[r]);
+    }
+    Dft<R>::run(v);
+    float2* __restrict__ dst = out + (size_t)row * L + base;
+#pragma unroll
+    for (int k = 0; k < R; ++k) dst[(size_t)k * Ns] = v[k];
+  }
+}
+
+// Bin kk (0 <= kk <= Nh) of the length-N real transform from the length-Nh transform Z of the
+// packed row: X = E + w^kk O, E = (Z[kk] + conj Z[Nh-kk])/2, O = -i (Z[kk] - conj Z[Nh-kk])/2.
+__device__ __forceinline__ float2 real_bin(const float2* __restrict__ Z, long long Nh, long long kk) {
+  const float2 a = Z[kk == Nh ? 0 : kk];
+  const float2 bz = Z[kk == 0 ? 0 : Nh - kk];
+  const float2 E = {0.5f * (a.x + bz.x), 0.5f * (a.y - bz.y)};
+  const float2 O = {0.5f * (a.y + bz.y), -0.5f * (a.x - bz.x)};
+  double s, c;
+  sincospi(-(double)kk / (double)Nh, &s, &c);  // exp(-2 pi i kk / N), N = 2 Nh
+  const float2 wO = cmulf(O, float2{(float)c, (float)s});
+  return {E.x + wO.x, E.y + wO.y};
+}
+
+// One thread per k < Mh: the two output-spectrum bins k and Mh-k (copied from the input
+// spectrum below nyq, the shared Nyquist bin scaled, zero above), combined into bin k of the
+// packed inverse transform, Z'[k] = (A + conj B) + i exp(2 pi i k / M) (A - conj B), and stored
+// conjugated (the inverse transform runs as a forward one).
+__global__ void resize_packed_kernel(const float2* __restrict__ Zin, long long Nh, long long Mh,
+                                     long long rows, long long nyq, long long shared_bin,
+                                     float shared_scale, float2* __restrict__ Zout) {
+  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= rows * Mh) return;
+  const long long row = g / Mh, k = g - row * Mh;
+  const float2* __restrict__ Z = Zin + row * Nh;
+  auto bin = [&](long long kk) {
+    float2 X = {0.0f, 0.0f};
+    if (kk < nyq) {
+      X = real_bin(Z, Nh, kk);
+      if (kk == shared_bin) X = {X.x * shared_scale, X.y * shared_scale};
+      if (kk == 0 || kk == Mh) X.y = 0.0f;
+    }
+    return X;
+  };
+  const float2 A = bin(k);
+  const float2 B = bin(Mh - k);
+  const float2 S = {A.x + B.x, A.y - B.y};  // A + conj B
+  const float2 D = {A.x - B.x, A.y + B.y};  // A - conj B
+  double s, c;
+  sincospi((double)k / (double)Mh, &s, &c);  // exp(+2 pi i k / M), M = 2 Mh
+  const float2 wD = cmulf(D, float2{(float)c, (float)s});
+  // Z' = S + i wD;  store conj(Z')
+  Zout[g] = {S.x - wD.y, -(S.y + wD.x)};
+}
+
+// y[2n] + i y[2n+1] = conj(F[n]) * scale.
+__global__ void unpack_real_kernel(const float2* __restrict__ F, long long total, float scale,
+                                   float2* __restrict__ y) {
+  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= total) return;
+  const float2 f = F[g];
+  y[g] = {f.x * scale, -f.y * scale};
+}
+
+// Radices of a mixed-radix plan for length L, largest butterflies first; 0 if L has a prime
+// factor other than 2, 3, 5, 7.
+static int plan_radices(long long L, int* radices) {
+  static const int cand[] = {16, 15, 12, 10, 8, 7, 6, 5, 4, 3, 2};
+  int n = 0;
+  while (L > 1) {
+    bool found = false;
+    for (int c : cand) {
+      if (L % c == 0) {
+        radices[n++] = c;
+        L /= c;
+        found = true;
+        break;
+      }
+    }
+    if (!found) return 0;
+    if (n >= 32) return 0;
+  }
+  return n;
+}
+static bool direct_ok(long long n_in, long long n_out) {
+  int r[32];
+  if (n_in % 2 || n_out % 2) return false;
+  if (n_in / 2 > 1 && plan_radices(n_in / 2, r) == 0) return false;
+  if (n_out / 2 > 1 && plan_radices(n_out / 2, r) == 0) return false;
+  return true;
+}
+
+// Forward FFT of `rows` rows of length L from `in` through the two buffers; `in` may be
+// bufB but not bufA.  *result = where the transform ends up (`in` itself when L == 1).
+static int fft_any(const float2* in, float2* bufA, float2* bufB, long long L, long long rows,
+                   hipStream_t s, const float2** result) {
+  int radices[32];
+  const int n = L > 1 ? plan_radices(L, radices) : 0;
+  if (L > 1 && n == 0) {
+    set_error("internal: length %lld is not 2-3-5-7 smooth", L);
+    return MIA_ERR_UNSUPPORTED;
+  }
+  const float2* src = in;
+  float2* dst = bufA;
+  unsigned Ns = 1;
+  const unsigned gy = (unsigned)(rows < 32768 ? rows : 32768);
+  for (int i = 0; i < n; ++i) {
+    const int R = radices[i];
+    const dim3 grid((unsigned)((L / R + 255) / 256), gy);
+#define MIA_PASS(RR) \
+  case RR: hipLaunchKernelGGL((stockham_any_kernel<RR>), grid, dim3(256), 0, s, src, dst, (unsigned)L, Ns, rows); break;
+    switch (R) {
+      MIA_PASS(16) MIA_PASS(15) MIA_PASS(12) MIA_PASS(10) MIA_PASS(8) MIA_PASS(7)
+      MIA_PASS(6) MIA_PASS(5) MIA_PASS(4) MIA_PASS(3) MIA_PASS(2)
+      default: break;
+    }
+#undef MIA_PASS
+    MIA_CHECK_HIP(hipGetLastError());
+    Ns *= (unsigned)R;
+    src = dst;
+    dst = dst == bufA ? bufB : bufA;
+  }
+  *result = src;
+  return MIA_OK;
+}
+
 static int ceil_log2(long long v) {
   int p = 0;
   while ((1LL << p) < v) ++p;
@@ -221,11 +379,16 @@ extern "C" {
 
 size_t mia_resample_fft_table_bytes(int64_t n_in, int64_t n_out) {
   if (n_in < 1 || n_out < 1 || n_in > (1LL << 27) || n_out > (1LL << 27)) return 0;
+  if (mia::direct_ok(n_in, n_out)) return sizeof(float2);  // no tables on the direct path
   return mia::rf_layout(n_in, n_out).table_elems * sizeof(float2);
 }
 
 size_t mia_resample_fft_workspace_bytes(int64_t rows, int64_t n_in, int64_t n_out) {
   if (rows < 1 || n_in < 1 || n_out < 1 || n_in > (1LL << 27) || n_out > (1LL << 27)) return 0;
+  if (mia::direct_ok(n_in, n_out)) {
+    const int64_t h = (n_in > n_out ? n_in : n_out) / 2;
+    return 2 * (size_t)rows * (size_t)h * sizeof(float2);
+  }
   return 2 * (size_t)rows * (size_t)mia::rf_layout(n_in, n_out).Lmax * sizeof(float2);
 }
 
@@ -238,6 +401,7 @@ int mia_resample_fft_tables(int64_t n_in, int64_t n_out, void* tables, void* wor
     return MIA_ERR_UNSUPPORTED;
   }
   MIA_REQUIRE(tables && workspace, "null pointer");
+  if (direct_ok(n_in, n_out)) return MIA_OK;
   const RfLayout l = rf_layout(n_in, n_out);
   MIA_REQUIRE(workspace_bytes >= 2 * (size_t)l.Lmax * sizeof(float2),
               "workspace too small: %zu bytes, need %zu", workspace_bytes,
@@ -276,6 +440,37 @@ int mia_resample_fft(const float* x, int64_t rows, int64_t n_in, int64_t n_out, 
   }
   if (rows == 0) return MIA_OK;
   MIA_REQUIRE(x && tables && out && workspace, "null pointer");
+  if (direct_ok(n_in, n_out) && (((uintptr_t)x | (uintptr_t)out) & 7) == 0) {
+    const long long Nh = n_in / 2, Mh = n_out / 2, H = Nh > Mh ? Nh : Mh;
+    const size_t need_d = 2 * (size_t)rows * (size_t)H * sizeof(float2);
+    MIA_REQUIRE(workspace_bytes >= need_d, "workspace too small: %zu bytes, need %zu",
+                workspace_bytes, need_d);
+    hipStream_t sd = (hipStream_t)stream;
+    float2* w0 = (float2*)workspace;
+    float2* w1 = w0 + (size_t)rows * H;
+    const float2* Z = nullptr;
+    int rcd = fft_any(reinterpret_cast<const float2*>(x), w0, w1, Nh, rows, sd, &Z);
+    if (rcd != MIA_OK) return rcd;
+    float2* Zp = Z == w0 ? w1 : w0;
+    const long long Nmin = n_in < n_out ? n_in : n_out;
+    long long shared_bin = -1;
+    float shared_scale = 1.0f;
+    if (n_in != n_out) {  // both even here, so the shorter length always has a Nyquist bin
+      shared_bin = Nmin / 2;
+      shared_scale = n_out < n_in ? 2.0f : 0.5f;
+    }
+    hipLaunchKernelGGL(resize_packed_kernel, dim3(blocks_for(rows * Mh)), dim3(256), 0, sd, Z, Nh,
+                       Mh, (long long)rows, Nmin / 2 + 1, shared_bin, shared_scale, Zp);
+    MIA_CHECK_HIP(hipGetLastError());
+    const float2* F = nullptr;
+    rcd = fft_any(Zp, Zp == w0 ? w1 : w0, Zp, Mh, rows, sd, &F);
+    if (rcd != MIA_OK) return rcd;
+    hipLaunchKernelGGL(unpack_real_kernel, dim3(blocks_for(rows * Mh)), dim3(256), 0, sd, F,
+                       (long long)rows * Mh, (float)((double)gain / (double)n_in),
+                       reinterpret_cast<float2*>(out));
+    MIA_CHECK_HIP(hipGetLastError());
+    return MIA_OK;
+  }
   const RfLayout l = rf_layout(n_in, n_out);
   const size_t need = 2 * (size_t)rows * (size_t)l.Lmax * sizeof(float2);
   MIA_REQUIRE(workspace_bytes >= need, "workspace too small: %zu bytes, need %zu", workspace_bytes,

@@ -219,6 +219,28 @@ struct DftCT {
   }
 };
 
+// Prime length by the definition (all twiddles compile-time constants); used for 7.
+template <int P>
+struct DftDirect {
+  static __device__ __forceinline__ void run(float2 (&v)[P]) {
+    float2 o[P];
+    static_for<0, P>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      float2 acc = v[0];
+      static_for<1, P>([&](auto nc) {
+        constexpr int n = decltype(nc)::value;
+        acc = cadd(acc, mul_w<n * k, P>(v[n]));
+      });
+      o[k] = acc;
+    });
+    static_for<0, P>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      v[k] = o[k];
+    });
+  }
+};
+template <> struct Dft<7> : DftDirect<7> {};
+
 template <> struct Dft<6> : DftCT<2, 3> {};
 template <> struct Dft<8> : DftCT<2, 4> {};
 template <> struct Dft<10> : DftCT<2, 5> {};

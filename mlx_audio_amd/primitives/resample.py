@@ -94,7 +94,7 @@ def resample(y, orig_sr: int, target_sr: int, res_type: str = "fft", fix: bool =
     return _restore(out, is_1d, axis)
 
 
-_FFT_WORKSPACE_BYTES = 2 << 30  # rows are processed in chunks that keep the workspace below this
+_FFT_WORKSPACE_BYTES = 8 << 30  # rows are processed in chunks that keep the workspace below this
 _fft_tables_cache: dict = {}
 
 

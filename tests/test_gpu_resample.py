@@ -264,17 +264,29 @@ def test_c_abi_argument_checks(gpu):
     assert lib.mia_resample_linear(x.data_ptr(), 1, 8, 4, 5.0, 1.0, out.data_ptr(),
                                    s) == _lib.MIA_ERR_INVALID   # would read past the row
     assert lib.mia_resample_linear(x.data_ptr(), 1, 8, 0, 0.0, 1.0, out.data_ptr(), s) == _lib.MIA_OK
-    # Fourier method: sizes, workspace
-    assert lib.mia_resample_fft_table_bytes(8, 4) == 8 * (8 + 4 + 16 + 8)
-    assert lib.mia_resample_fft_workspace_bytes(3, 8, 4) == 2 * 3 * 16 * 8
+    # Fourier method: sizes, workspace.  Odd lengths take the chirp-z path (tables: both chirps
+    # and both filter spectra; workspace: two buffers of the longer convolution), even lengths
+    # with 2-3-5-7-smooth halves the direct path (no tables, two half-length buffers).
+    assert lib.mia_resample_fft_table_bytes(9, 5) == 8 * (9 + 5 + 32 + 16)
+    assert lib.mia_resample_fft_workspace_bytes(3, 9, 5) == 2 * 3 * 32 * 8
+    assert lib.mia_resample_fft_table_bytes(8, 4) == 8
+    assert lib.mia_resample_fft_workspace_bytes(3, 8, 4) == 2 * 3 * 4 * 8
     assert lib.mia_resample_fft_table_bytes(1 << 28, 4) == 0
-    tab8 = torch.zeros(lib.mia_resample_fft_table_bytes(8, 4), dtype=torch.uint8, device=gpu)
-    work = torch.zeros(lib.mia_resample_fft_workspace_bytes(1, 8, 4), dtype=torch.uint8, device=gpu)
-    assert lib.mia_resample_fft_tables(8, 4, tab8.data_ptr(), work.data_ptr(), work.numel(), s) == _lib.MIA_OK
-    assert lib.mia_resample_fft(x.data_ptr(), 1, 8, 4, 1.0, tab8.data_ptr(), out.data_ptr(),
-                                work.data_ptr(), work.numel() - 1, s) == _lib.MIA_ERR_INVALID
-    assert b"workspace too small" in lib.mia_last_error()
-    assert lib.mia_resample_fft(x.data_ptr(), 1, 8, 4, 1.0, tab8.data_ptr(), out.data_ptr(),
-                                work.data_ptr(), work.numel(), s) == _lib.MIA_OK
-    assert lib.mia_resample_fft(x.data_ptr(), 1, 0, 4, 1.0, tab8.data_ptr(), out.data_ptr(),
+    x9 = torch.arange(9, device=gpu, dtype=torch.float32)
+    for n_in, n_out in ((9, 5), (8, 4)):
+        tab = torch.zeros(lib.mia_resample_fft_table_bytes(n_in, n_out), dtype=torch.uint8, device=gpu)
+        work = torch.zeros(lib.mia_resample_fft_workspace_bytes(1, n_in, n_out), dtype=torch.uint8,
+                           device=gpu)
+        assert lib.mia_resample_fft_tables(n_in, n_out, tab.data_ptr(), work.data_ptr(),
+                                           work.numel(), s) == _lib.MIA_OK
+        assert lib.mia_resample_fft(x9.data_ptr(), 1, n_in, n_out, 1.0, tab.data_ptr(),
+                                    out.data_ptr(), work.data_ptr(), work.numel() - 1,
+                                    s) == _lib.MIA_ERR_INVALID
+        assert b"workspace too small" in lib.mia_last_error()
+        assert lib.mia_resample_fft(x9.data_ptr(), 1, n_in, n_out, 1.0, tab.data_ptr(),
+                                    out.data_ptr(), work.data_ptr(), work.numel(), s) == _lib.MIA_OK
+        torch.cuda.synchronize()
+        want = orc.resample(x9[:n_in].cpu().numpy(), n_in, n_out)
+        np.testing.assert_allclose(out[:n_out].cpu().numpy(), want, rtol=0, atol=1e-5)
+    assert lib.mia_resample_fft(x9.data_ptr(), 1, 0, 4, 1.0, tab.data_ptr(), out.data_ptr(),
                                 work.data_ptr(), work.numel(), s) == _lib.MIA_ERR_INVALID
