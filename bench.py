@@ -14,6 +14,7 @@ Workloads (config.workload):
   htdemucs    16 stereo x 60 s @44.1 kHz STFT+iSTFT round trip, n_fft 4096 / hop 1024
   resample    512 x 30 s @44.1 kHz -> 16 kHz, polyphase (up 160 / down 441)
   resample_fft 64 x 30 s @44.1 kHz -> 16 kHz, Fourier method (the reference's default)
+  features    centroid + bandwidth + roll-off + flatness of a (512, 1025, 938) spectrogram
 """
 
 from __future__ import annotations
@@ -93,6 +94,23 @@ def make_workload(name: str, clips: int, device, seed: int):
         return (lambda: resample(y, 44100, 16000), clips * 30.0 / 3600.0, abytes,
                 f"Fourier-method resampling 44.1 kHz -> 16 kHz (rfft 1 323 000 -> irfft 480 000 "
                 f"per clip), {clips} x 30 s clips", "resample(fft) audio-hours/sec (44.1k -> 16k)")
+    if name == "features":
+        from mlx_audio_amd.primitives import (spectral_bandwidth, spectral_centroid,
+                                              spectral_flatness, spectral_rolloff)
+
+        S = torch.rand((clips, 1025, 938), generator=gen, device=device, dtype=torch.float32) + 0.05
+        # every statistic reads the spectrogram once (the roll-off twice) and writes one row
+        abytes = 4 * clips * (1025 * 938 * 4 + 938 * 4)
+
+        def step():
+            c = spectral_centroid(S=S, sr=16000)
+            return (c, spectral_bandwidth(S=S, sr=16000, centroid=c), spectral_rolloff(S=S, sr=16000),
+                    spectral_flatness(S=S))
+
+        return (step, clips * 30.0 / 3600.0, abytes,
+                f"spectral centroid + bandwidth + roll-off + flatness of {clips} spectrograms "
+                "(1025 bins x 938 frames = 30 s @16 kHz, n_fft 2048 hop 512)",
+                "spectral features audio-hours/sec (4 statistics)")
     raise SystemExit(f"unknown workload {name}")
 
 
@@ -102,6 +120,7 @@ KERNEL_OF = {
     "mfcc40": "fwd_kernel<2048, mel> (fused rFFT+mel+dB) followed by dct2_mfma_kernel",
     "htdemucs": "fwd_kernel<4096> then istft_kernel<4096> (fused inverse FFT + overlap-add)",
     "resample": "upfirdn_kernel (polyphase FIR, input span and phase table staged in LDS)",
+    "features": "spectral_stat_kernel x 4 (one thread per frame, bins walked in order)",
     "resample_fft": "stockham_pass_kernel<16> x 22 + chirp / spectrum kernels (two chirp-z "
                     "convolutions per clip)",
 }
@@ -199,7 +218,7 @@ def main() -> None:
               "torch.distributed.run for N>1", file=sys.stderr)
 
     default_clips = {"whisper128": 1024, "clap64": 1024, "mfcc40": 1024, "htdemucs": 32,
-                     "resample": 512, "resample_fft": 64}
+                     "resample": 512, "resample_fft": 64, "features": 512}
     clips = args.clips or default_clips.get(args.workload, 1024)
     step, units, abytes, desc, metric = make_workload(args.workload, clips, device, 1234 + rank)
 
@@ -263,7 +282,7 @@ def main() -> None:
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic white Gaussian noise generated on device",
+            "data": "synthetic (random, generated on device; see config.workload)",
             "config": {"workload": desc, "clips_per_gpu": clips,
                        "parallelism": f"clips sharded over {n_gpus} GPU(s), no collective",
                        "clock_warmup_ms": clock_warmup_ms},

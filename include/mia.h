@@ -230,6 +230,31 @@ int mia_resample_fft(const float* x, int64_t rows, int64_t n_in, int64_t n_out, 
                      const void* tables, float* out, void* workspace, size_t workspace_bytes,
                      void* stream);
 
+/* ---- spectral features (primitives/features.py) -------------------------------------
+ * Per-frame statistics over the frequency axis of S: device (rows, bins, frames), frames
+ * contiguous; freq: device (bins) bin frequencies; out: device (rows, frames).
+ *   MIA_STAT_CENTROID   spectral_centroid  (features.py:59-136): sum(f S) / (sum S + 1e-8)
+ *   MIA_STAT_BANDWIDTH  spectral_bandwidth (features.py:139-241): aux = centroid (rows, frames);
+ *                       (sum(S |f - c|^p) / (sum S + 1e-8))^(1/p), unnormalised if norm == 0
+ *   MIA_STAT_ROLLOFF    spectral_rolloff   (features.py:244-382, _ext.spectral_rolloff):
+ *                       f of the first bin whose running sum reaches fraction * total
+ *   MIA_STAT_FLATNESS   spectral_flatness  (features.py:385-464): geometric / arithmetic mean of
+ *                       max(S^power, amin) (power = 1 when S already is the power spectrogram) */
+#define MIA_STAT_CENTROID 0
+#define MIA_STAT_BANDWIDTH 1
+#define MIA_STAT_ROLLOFF 2
+#define MIA_STAT_FLATNESS 3
+int mia_spectral_stat(const float* S, int64_t rows, int bins, int64_t frames, const float* freq,
+                      const float* aux, int mode, float p, int norm, float fraction, float amin,
+                      float power, float* out, void* stream);
+/* zero_crossing_rate (features.py:642-769): y device (rows, n); frames of frame_length every
+ * hop_length samples after centre padding (zeros, or the edge sample if pad_edge) when
+ * `center`; out device (rows, 1 + (n + 2*pad - frame_length) / hop_length) = sign changes
+ * inside the frame / frame_length; sign = (x >= 0), or the IEEE sign bit if by_signbit
+ * (the reference's use_mlx=False variant). */
+int mia_zero_crossing_rate(const float* y, int64_t rows, int64_t n, int frame_length, int hop_length,
+                           int center, int pad_edge, int by_signbit, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

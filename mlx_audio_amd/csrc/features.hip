@@ -1,0 +1,168 @@
+// Per-frame spectral statistics of a magnitude / power spectrogram laid out (rows, bins,
+// frames) with frames contiguous, and the zero-crossing rate of framed signals.
+//
+// Statistics: one thread per frame; consecutive lanes hold consecutive frames, so every
+// load of bin k is one coalesced row segment and each thread walks the bins in order with
+// its own float32 accumulators (the summation order of a sequential reduction over the
+// frequency axis).  The spectrogram is read once (twice for the roll-off frequency: total,
+// then the running sum).  Zero crossings: one wave per frame, lanes striding the samples.
+#include "mia_internal.h"
+
+namespace mia {
+
+constexpr float kDivEps = 1e-8f;  // the reference's DIVISION_EPSILON
+
+__device__ __forceinline__ float pow_in(float v, int power_mode, float power) {
+  if (power_mode == 0) return v;
+  if (power_mode == 1) return v * v;
+  return powf(v, power);
+}
+
+// mode 0: centroid  sum(f S) / (sum S + eps)
+// mode 1: bandwidth (sum(S |f - c|^p) [/ (sum S + eps)])^(1/p), c = aux[row, frame]
+// mode 2: roll-off  f[first k with cumsum_k >= fraction * total], last bin if none
+// mode 3: flatness  exp(mean log max(S^power, amin)) / (mean max(S^power, amin) + eps)
+__global__ __launch_bounds__(256) void spectral_stat_kernel(
+    const float* __restrict__ S, long long rows, int bins, long long F,
+    const float* __restrict__ freq, const float* __restrict__ aux, int mode, float p, int norm,
+    float fraction, float amin, int power_mode, float power, float* __restrict__ out) {
+  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= rows * F) return;
+  const long long row = g / F, f = g - row * F;
+  const float* __restrict__ col = S + row * bins * F + f;
+  float result = 0.0f;
+  if (mode == 0) {
+    float ws = 0.0f, ts = 0.0f;
+#pragma unroll 8
+    for (int k = 0; k < bins; ++k) {
+      const float v = col[(long long)k * F];
+      ws += freq[k] * v;
+      ts += v;
+    }
+    result = ws / (ts + kDivEps);
+  } else if (mode == 1) {
+    const float c = aux[g];
+    float ws = 0.0f, ts = 0.0f;
+#pragma unroll 8
+    for (int k = 0; k < bins; ++k) {
+      const float v = col[(long long)k * F];
+      const float d = fabsf(freq[k] - c);
+      const float dp = p == 2.0f ? d * d : (p == 1.0f ? d : powf(d, p));
+      ws += v * dp;
+      ts += v;
+    }
+    if (norm) ws = ws / (ts + kDivEps);
+    result = p == 2.0f ? sqrtf(ws) : (p == 1.0f ? ws : powf(ws, 1.0f / p));
+  } else if (mode == 2) {
+    float total = 0.0f;
+#pragma unroll 8
+    for (int k = 0; k < bins; ++k) total += col[(long long)k * F];
+    const float thr = fraction * total;
+    float cs = 0.0f;
+    int hit = bins - 1;
+    bool open = true;
+#pragma unroll 8
+    for (int k = 0; k < bins; ++k) {
+      cs += col[(long long)k * F];
+      if (open && cs >= thr) {
+        hit = k;
+        open = false;
+      }
+    }
+    result = freq[hit];
+  } else {
+    float ls = 0.0f, as = 0.0f;
+#pragma unroll 8
+    for (int k = 0; k < bins; ++k) {
+      float v = pow_in(col[(long long)k * F], power_mode, power);
+      v = v < amin ? amin : v;  // a NaN stays a NaN, as in maximum(S, amin)
+      ls += logf(v);
+      as += v;
+    }
+    result = expf(ls / (float)bins) / (as / (float)bins + kDivEps);
+  }
+  out[g] = result;
+}
+
+// out[row, frame] = (number of i in 1..L-1 with sign(x[i]) != sign(x[i-1])) / L over the
+// frame's L samples; sign = (x >= 0) or, with by_signbit, the IEEE sign bit.  Centre padding
+// (pad samples on both sides) by zeros or by the edge sample.
+__global__ __launch_bounds__(256) void zcr_kernel(const float* __restrict__ y, long long rows,
+                                                  long long T, int L, int hop, long long pad,
+                                                  int pad_edge, int by_signbit, long long F,
+                                                  float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (wave >= rows * F) return;
+  const long long row = wave / F, f = wave - row * F;
+  const float* __restrict__ yr = y + row * T;
+  const long long s0 = f * hop - pad;
+  auto sample = [&](long long i) {
+    if (i >= 0 && i < T) return yr[i];
+    return pad_edge ? yr[i < 0 ? 0 : T - 1] : 0.0f;
+  };
+  auto positive = [&](float v) {
+    return by_signbit ? (__float_as_uint(v) >> 31) == 0u : v >= 0.0f;
+  };
+  int count = 0;
+  for (int i = 1 + lane; i < L; i += 64) {
+    count += positive(sample(s0 + i)) != positive(sample(s0 + i - 1)) ? 1 : 0;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) count += __shfl_xor(count, off);
+  if (lane == 0) out[wave] = (float)count / (float)L;
+}
+
+}  // namespace mia
+
+extern "C" {
+
+int mia_spectral_stat(const float* S, int64_t rows, int bins, int64_t frames, const float* freq,
+                      const float* aux, int mode, float p, int norm, float fraction, float amin,
+                      float power, float* out, void* stream) {
+  using namespace mia;
+  MIA_REQUIRE(rows >= 0 && bins >= 1 && frames >= 0, "rows, bins, frames must be >= 0, 1, 0");
+  MIA_REQUIRE(mode >= MIA_STAT_CENTROID && mode <= MIA_STAT_FLATNESS, "unknown statistic %d", mode);
+  if (rows == 0 || frames == 0) return MIA_OK;
+  MIA_REQUIRE(S && out, "null pointer");
+  MIA_REQUIRE(mode == MIA_STAT_FLATNESS || freq, "this statistic needs the bin frequencies");
+  MIA_REQUIRE(mode != MIA_STAT_BANDWIDTH || (aux && p > 0.0f),
+              "the bandwidth needs the centroid of every frame and p > 0");
+  const long long total = (long long)rows * frames;
+  if (total > 0x7fffffffLL * 256) {
+    set_error("%lld frames do not fit one launch (split the batch)", total);
+    return MIA_ERR_UNSUPPORTED;
+  }
+  const int power_mode = power == 1.0f ? 0 : (power == 2.0f ? 1 : 2);
+  hipLaunchKernelGGL(spectral_stat_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, S, (long long)rows, bins, (long long)frames, freq, aux,
+                     mode, p, norm, fraction, amin, power_mode, power, out);
+  MIA_CHECK_HIP(hipGetLastError());
+  return MIA_OK;
+}
+
+int mia_zero_crossing_rate(const float* y, int64_t rows, int64_t n, int frame_length, int hop_length,
+                           int center, int pad_edge, int by_signbit, float* out, void* stream) {
+  using namespace mia;
+  MIA_REQUIRE(rows >= 0 && n >= 1, "rows and n must be >= 0 and 1");
+  MIA_REQUIRE(frame_length >= 1 && hop_length >= 1, "frame_length and hop_length must be >= 1");
+  const long long pad = center ? frame_length / 2 : 0;
+  const long long padded = (long long)n + 2 * pad;
+  MIA_REQUIRE(padded >= frame_length, "Input signal length (%lld) must be >= frame_length (%d)",
+              padded, frame_length);
+  const long long F = 1 + (padded - frame_length) / hop_length;
+  if (rows == 0) return MIA_OK;
+  MIA_REQUIRE(y && out, "null pointer");
+  const long long waves = (long long)rows * F;
+  if (waves > 0x7fffffffLL * 4) {
+    set_error("%lld frames do not fit one launch (split the batch)", waves);
+    return MIA_ERR_UNSUPPORTED;
+  }
+  hipLaunchKernelGGL(zcr_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0,
+                     (hipStream_t)stream, y, (long long)rows, (long long)n, frame_length,
+                     hop_length, pad, pad_edge, by_signbit, F, out);
+  MIA_CHECK_HIP(hipGetLastError());
+  return MIA_OK;
+}
+
+}  // extern "C"

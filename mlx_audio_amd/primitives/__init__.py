@@ -3,6 +3,8 @@
 
 from .._lib import HAS_HIP_EXT, has_hip_extensions
 from .convert import amplitude_to_db, db_to_amplitude, db_to_power, power_to_db
+from .features import (spectral_bandwidth, spectral_centroid, spectral_contrast,
+                       spectral_flatness, spectral_rolloff, zero_crossing_rate)
 from .mel import hz_to_mel, mel_filterbank, mel_to_hz, melspectrogram
 from .mfcc import dct, mfcc
 from .resample import resample, resample_poly
@@ -16,4 +18,6 @@ __all__ = [
     "dct", "mfcc",
     "power_to_db", "amplitude_to_db", "db_to_power", "db_to_amplitude",
     "resample", "resample_poly",
+    "spectral_centroid", "spectral_bandwidth", "spectral_rolloff", "spectral_flatness",
+    "spectral_contrast", "zero_crossing_rate",
 ]

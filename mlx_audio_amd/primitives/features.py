@@ -1,0 +1,170 @@
+"""Spectral features on MI355X with the signatures of `mlx_audio.primitives.features`
+(reference python/mlx_audio/primitives/features.py): spectral_centroid, spectral_bandwidth,
+spectral_rolloff, spectral_flatness, zero_crossing_rate.  `spectral_contrast` (per-band
+quantiles, features.py:467-639) is not built and says so.
+
+Each statistic is one kernel launch over the (rows, bins, frames) spectrogram; from a waveform
+the spectrogram comes from this package's `stft` + `magnitude`.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from .. import _lib
+from .._runtime import as_device_f32, require_gpu, stream_ptr
+from .stft import magnitude, stft
+
+_STAT = {"centroid": 0, "bandwidth": 1, "rolloff": 2, "flatness": 3}
+
+
+def _get_frequencies(sr, n_fft: int) -> np.ndarray:
+    """Bin centre frequencies (features.py:21-23)."""
+    return np.linspace(0, sr / 2.0, n_fft // 2 + 1).astype(np.float32)
+
+
+def _compute_spectrogram(y, S, n_fft, hop_length, win_length, window, center, pad_mode):
+    """Magnitude spectrogram unless one is given (features.py:26-56)."""
+    if S is not None:
+        require_gpu()
+        if not isinstance(S, torch.Tensor):
+            S = torch.as_tensor(np.asarray(S))
+        if not S.is_cuda:
+            S = S.to("cuda")
+        return S.to(torch.float32)
+    if y is None:
+        raise ValueError("Either y (audio) or S (spectrogram) must be provided")
+    return magnitude(stft(y, n_fft=n_fft, hop_length=hop_length, win_length=win_length,
+                          window=window, center=center, pad_mode=pad_mode))
+
+
+_freq_dev_cache: dict = {}
+
+
+def _default_freq_dev(sr, n_fft: int, device) -> torch.Tensor:
+    """Device copy of the default bin frequencies, kept per (sr, n_fft, device)."""
+    key = (float(sr), int(n_fft), device.index)
+    t = _freq_dev_cache.get(key)
+    if t is None:
+        if len(_freq_dev_cache) >= 64:
+            _freq_dev_cache.clear()
+        t = torch.from_numpy(_get_frequencies(sr, n_fft)).to(device)
+        _freq_dev_cache[key] = t
+    return t
+
+
+def _dev_vector(v, device) -> torch.Tensor:
+    if isinstance(v, torch.Tensor):
+        return v.to(device=device, dtype=torch.float32).contiguous()
+    return torch.from_numpy(np.ascontiguousarray(np.asarray(v, dtype=np.float32))).to(device)
+
+
+def _stat(S: torch.Tensor, kind: str, freq=None, aux=None, p=2.0, norm=True, fraction=0.0,
+          amin=0.0, power=1.0) -> torch.Tensor:
+    """Runs one statistic over S (rows, bins, frames) or (bins, frames); keeps the reference's
+    output shapes: (rows, 1, frames) or (1, frames)."""
+    batched = S.dim() == 3
+    Sb = (S if batched else S[None]).contiguous()
+    if Sb.dim() != 3:
+        raise ValueError(f"expected a 2-D or 3-D spectrogram, got {S.dim()}-D")
+    rows, bins, frames = Sb.shape
+    dev = Sb.device
+    fdev = None
+    if freq is not None:
+        fdev = _dev_vector(freq, dev)
+        if fdev.numel() != bins:
+            raise ValueError(f"freq has {fdev.numel()} entries but the spectrogram has {bins} bins")
+    adev = None
+    if aux is not None:
+        adev = _dev_vector(aux, dev).reshape(-1)
+        if adev.numel() != rows * frames:
+            raise ValueError("centroid must hold one value per frame")
+    out = torch.empty((rows, 1, frames), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().mia_spectral_stat(
+            Sb.data_ptr(), rows, bins, frames, 0 if fdev is None else fdev.data_ptr(),
+            0 if adev is None else adev.data_ptr(), _STAT[kind], float(p), int(bool(norm)),
+            float(fraction), float(amin), float(power), out.data_ptr(), stream_ptr(dev)))
+    return out if batched else out[0]
+
+
+def spectral_centroid(y=None, sr: int = 22050, S=None, n_fft: int = 2048, hop_length: int = 512,
+                      win_length=None, window="hann", center: bool = True,
+                      pad_mode: str = "constant", freq=None) -> torch.Tensor:
+    """Centre of mass of the spectrum per frame (reference features.py:59-136)."""
+    S = _compute_spectrogram(y, S, n_fft, hop_length, win_length, window, center, pad_mode)
+    if freq is None:
+        freq = _default_freq_dev(sr, n_fft, S.device)
+    return _stat(S, "centroid", freq=freq)
+
+
+def spectral_bandwidth(y=None, sr: int = 22050, S=None, n_fft: int = 2048, hop_length: int = 512,
+                       win_length=None, window="hann", center: bool = True,
+                       pad_mode: str = "constant", freq=None, centroid=None, p: float = 2.0,
+                       norm: bool = True) -> torch.Tensor:
+    """Spread of the spectrum around its centroid (reference features.py:139-241)."""
+    S = _compute_spectrogram(y, S, n_fft, hop_length, win_length, window, center, pad_mode)
+    if freq is None:
+        freq = _default_freq_dev(sr, n_fft, S.device)
+    if centroid is None:
+        centroid = _stat(S, "centroid", freq=freq)
+    return _stat(S, "bandwidth", freq=freq, aux=centroid, p=p, norm=norm)
+
+
+def spectral_rolloff(y=None, sr: int = 22050, S=None, n_fft: int = 2048, hop_length: int = 512,
+                     win_length=None, window="hann", center: bool = True,
+                     pad_mode: str = "constant", freq=None, roll_percent: float = 0.85,
+                     use_cpp: bool = True) -> torch.Tensor:
+    """Frequency below which `roll_percent` of the energy lies (reference features.py:296-382).
+    `use_cpp` is accepted for signature compatibility; there is one implementation here."""
+    if roll_percent < 0.0:
+        raise ValueError(f"roll_percent must be >= 0.0, got {roll_percent}")
+    if roll_percent > 1.0:
+        raise ValueError(f"roll_percent must be <= 1.0, got {roll_percent}")
+    S = _compute_spectrogram(y, S, n_fft, hop_length, win_length, window, center, pad_mode)
+    if freq is None:
+        freq = _default_freq_dev(sr, n_fft, S.device)
+    return _stat(S, "rolloff", freq=freq, fraction=roll_percent)
+
+
+def spectral_flatness(y=None, S=None, n_fft: int = 2048, hop_length: int = 512, win_length=None,
+                      window="hann", center: bool = True, pad_mode: str = "constant",
+                      power: float = 2.0, amin: float = 1e-10) -> torch.Tensor:
+    """Wiener entropy per frame (reference features.py:385-464).  `power` applies to the
+    magnitude computed from `y`; a spectrogram passed as `S` is used as it is."""
+    from_y = S is None
+    S = _compute_spectrogram(y, S, n_fft, hop_length, win_length, window, center, pad_mode)
+    return _stat(S, "flatness", amin=amin, power=power if from_y else 1.0)
+
+
+def spectral_contrast(*args, **kwargs):
+    """Per-band peak/valley contrast (reference features.py:467-639): not built."""
+    raise NotImplementedError("spectral_contrast is not built yet")
+
+
+def zero_crossing_rate(y, frame_length: int = 2048, hop_length: int = 512, center: bool = True,
+                       pad_mode: str = "edge", use_mlx: bool = True) -> torch.Tensor:
+    """Fraction of sign changes per frame (reference features.py:672-769).  `use_mlx=True`
+    takes the sign as x >= 0, `False` as the IEEE sign bit (they differ for -0.0 and NaN)."""
+    if frame_length <= 0:
+        raise ValueError(f"frame_length must be positive, got {frame_length}")
+    if hop_length <= 0:
+        raise ValueError(f"hop_length must be positive, got {hop_length}")
+    if center and pad_mode not in ("constant", "edge"):
+        raise ValueError(f"Unknown pad_mode: '{pad_mode}'. Supported: 'constant', 'edge'")
+    x = as_device_f32(y)
+    is_1d = x.dim() == 1
+    xb = x[None] if is_1d else x
+    rows, n = xb.shape
+    padded = n + (2 * (frame_length // 2) if center else 0)
+    if padded < frame_length:
+        raise ValueError(
+            f"Input signal length ({padded}) must be >= frame_length ({frame_length})")
+    frames = 1 + (padded - frame_length) // hop_length
+    out = torch.empty((rows, 1, frames), dtype=torch.float32, device=xb.device)
+    with torch.cuda.device(xb.device):
+        _lib.check(_lib.lib().mia_zero_crossing_rate(
+            xb.data_ptr(), rows, n, frame_length, hop_length, int(bool(center)),
+            int(pad_mode == "edge"), int(not use_mlx), out.data_ptr(), stream_ptr(xb.device)))
+    return out[0] if is_1d else out

@@ -1,0 +1,155 @@
+"""Spectral features on the GPU against the oracle (float32 NumPy restatement of the
+reference), through the C ABI.  Tolerances: float32 sums over up to 2049 bins in a different
+order (1e-5 relative); the roll-off frequency may land one bin away when the running sum and
+the threshold agree to the last bits (the reference itself changes there with the order of
+its cumulative sum)."""
+
+import numpy as np
+import pytest
+import torch
+
+import oracle.features as orc
+from mlx_audio_amd import _lib
+from mlx_audio_amd.primitives import (spectral_bandwidth, spectral_centroid, spectral_flatness,
+                                      spectral_rolloff, zero_crossing_rate)
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 2e-5
+
+
+def _dev(a, gpu):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(gpu)
+
+
+def _spec(rng, shape):
+    return (rng.standard_normal(shape).astype(np.float32) ** 2 + 0.01).astype(np.float32)
+
+
+@pytest.mark.parametrize("shape", [(1025, 44), (3, 1025, 44), (2, 513, 301), (5, 9, 1), (1, 2049, 130)])
+def test_statistics_from_a_spectrogram(gpu, shape):
+    rng = np.random.default_rng(sum(shape))
+    S = _spec(rng, shape)
+    bins = shape[-2]
+    sr, n_fft = 22050, 2 * (bins - 1)
+    Sd = _dev(S, gpu)
+    got = spectral_centroid(S=Sd, sr=sr, n_fft=n_fft).cpu().numpy()
+    want = orc.spectral_centroid(S=S, sr=sr, n_fft=n_fft)
+    assert got.shape == want.shape
+    np.testing.assert_allclose(got, want, rtol=RTOL)
+    for p, norm in ((2.0, True), (1.0, True), (3.0, True), (2.0, False)):
+        got = spectral_bandwidth(S=Sd, sr=sr, n_fft=n_fft, p=p, norm=norm).cpu().numpy()
+        want = orc.spectral_bandwidth(S=S, sr=sr, n_fft=n_fft, p=p, norm=norm)
+        np.testing.assert_allclose(got, want, rtol=5e-5, err_msg=f"p={p} norm={norm}")
+    got = spectral_flatness(S=Sd).cpu().numpy()
+    np.testing.assert_allclose(got, orc.spectral_flatness(S=S), rtol=5e-5)
+    freq = orc.get_frequencies(sr, n_fft)
+    step = freq[1] - freq[0] if bins > 1 else 0.0
+    for roll in (0.85, 0.5, 0.0, 1.0):
+        got = spectral_rolloff(S=Sd, sr=sr, n_fft=n_fft, roll_percent=roll).cpu().numpy()
+        want = orc.spectral_rolloff(S=S, sr=sr, n_fft=n_fft, roll_percent=roll)
+        assert got.shape == want.shape
+        assert np.abs(got - want).max() <= step * 1.001, roll
+        assert (got != want).mean() <= 0.02, roll
+
+
+def test_custom_frequencies_and_given_centroid(gpu):
+    rng = np.random.default_rng(4)
+    S = _spec(rng, (2, 64, 20))
+    freq = np.sort(rng.uniform(0, 8000, 64)).astype(np.float32)
+    c = orc.spectral_centroid(S=S, freq=freq)
+    np.testing.assert_allclose(spectral_centroid(S=_dev(S, gpu), freq=freq).cpu().numpy(), c, rtol=RTOL)
+    got = spectral_bandwidth(S=_dev(S, gpu), freq=_dev(freq, gpu), centroid=_dev(c, gpu)).cpu().numpy()
+    np.testing.assert_allclose(got, orc.spectral_bandwidth(S=S, freq=freq, centroid=c), rtol=5e-5)
+    with pytest.raises(ValueError, match="freq has 10 entries"):
+        spectral_centroid(S=_dev(S, gpu), freq=freq[:10])
+
+
+@pytest.mark.parametrize("n_fft,hop", [(2048, 512), (1024, 256), (400, 160)])
+def test_statistics_from_a_waveform(gpu, n_fft, hop):
+    rng = np.random.default_rng(n_fft)
+    t = np.arange(22050) / 22050.0
+    y = (np.sin(2 * np.pi * 1500 * t) + 0.1 * rng.standard_normal(22050)).astype(np.float32)
+    yb = np.stack([y, rng.standard_normal(22050).astype(np.float32)])
+    kw = dict(n_fft=n_fft, hop_length=hop)
+    for fn, ofn, tol in ((spectral_centroid, orc.spectral_centroid, 1e-4),
+                         (spectral_bandwidth, orc.spectral_bandwidth, 2e-4)):
+        got = fn(_dev(yb, gpu), sr=22050, **kw).cpu().numpy()
+        want = ofn(yb, sr=22050, **kw)
+        assert got.shape == want.shape
+        np.testing.assert_allclose(got, want, rtol=tol)
+        np.testing.assert_allclose(fn(_dev(y, gpu), sr=22050, **kw).cpu().numpy(),
+                                   ofn(y, sr=22050, **kw), rtol=tol)
+    got = spectral_flatness(_dev(yb, gpu), **kw).cpu().numpy()
+    np.testing.assert_allclose(got, orc.spectral_flatness(yb, **kw), rtol=1e-3, atol=1e-9)
+    got = spectral_flatness(_dev(yb, gpu), power=1.0, **kw).cpu().numpy()
+    np.testing.assert_allclose(got, orc.spectral_flatness(yb, power=1.0, **kw), rtol=1e-3)
+    got = spectral_rolloff(_dev(yb, gpu), sr=22050, **kw).cpu().numpy()
+    want = orc.spectral_rolloff(yb, sr=22050, **kw)
+    assert np.abs(got - want).max() <= 22050 / n_fft * 1.001
+    assert (got != want).mean() <= 0.02
+
+
+@pytest.mark.parametrize("frame_length,hop", [(2048, 512), (256, 128), (100, 37), (1, 1)])
+def test_zero_crossing_rate_is_exact(gpu, frame_length, hop):
+    rng = np.random.default_rng(frame_length)
+    y = rng.standard_normal((3, 10000)).astype(np.float32)
+    y[0, 100:200] = 0.0
+    y[1, ::7] = -0.0
+    for center in (True, False):
+        for pad_mode in ("edge", "constant"):
+            for use_mlx in (True, False):
+                want = orc.zero_crossing_rate(y, frame_length, hop, center, pad_mode, use_mlx)
+                got = zero_crossing_rate(_dev(y, gpu), frame_length, hop, center, pad_mode, use_mlx)
+                assert got.shape == want.shape
+                np.testing.assert_array_equal(got.cpu().numpy(), want)
+    np.testing.assert_array_equal(zero_crossing_rate(_dev(y[2], gpu), frame_length, hop).cpu().numpy(),
+                                  orc.zero_crossing_rate(y[2], frame_length, hop))
+
+
+def test_short_signals_and_c_abi_checks(gpu):
+    with pytest.raises(ValueError, match="must be >= frame_length"):
+        zero_crossing_rate(_dev(np.zeros(10, np.float32), gpu), frame_length=64, center=False)
+    lib = _lib.lib()
+    S = torch.ones((4, 3), device=gpu)
+    out = torch.zeros(3, device=gpu)
+    f = torch.arange(4, device=gpu, dtype=torch.float32)
+    s = torch.cuda.current_stream(gpu).cuda_stream
+    assert lib.mia_spectral_stat(S.data_ptr(), 1, 4, 3, f.data_ptr(), 0, 7, 2.0, 1, 0.0, 0.0, 1.0,
+                                 out.data_ptr(), s) == _lib.MIA_ERR_INVALID
+    assert lib.mia_spectral_stat(S.data_ptr(), 1, 4, 3, 0, 0, 0, 2.0, 1, 0.0, 0.0, 1.0,
+                                 out.data_ptr(), s) == _lib.MIA_ERR_INVALID   # centroid without freq
+    assert lib.mia_spectral_stat(S.data_ptr(), 1, 4, 3, f.data_ptr(), 0, 1, 2.0, 1, 0.0, 0.0, 1.0,
+                                 out.data_ptr(), s) == _lib.MIA_ERR_INVALID   # bandwidth without centroid
+    assert lib.mia_spectral_stat(S.data_ptr(), 0, 4, 3, f.data_ptr(), 0, 0, 2.0, 1, 0.0, 0.0, 1.0,
+                                 out.data_ptr(), s) == _lib.MIA_OK
+    assert lib.mia_spectral_stat(S.data_ptr(), 1, 4, 3, f.data_ptr(), 0, 0, 2.0, 1, 0.0, 0.0, 1.0,
+                                 out.data_ptr(), s) == _lib.MIA_OK
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out.cpu().numpy(), 1.5, rtol=1e-6)
+    assert lib.mia_zero_crossing_rate(S.data_ptr(), 1, 12, 0, 1, 1, 1, 0, out.data_ptr(),
+                                      s) == _lib.MIA_ERR_INVALID
+
+
+def test_full_size_batch_properties(gpu):
+    """1024 x 30 s @16 kHz worth of frames (n_fft 2048, hop 512 -> 938 frames) as a power
+    spectrogram: spot rows against the oracle; scaling laws on all rows (centroid, roll-off and
+    flatness do not change when the spectrogram is scaled, bandwidth neither)."""
+    g = torch.Generator(device=gpu)
+    g.manual_seed(3)
+    S = torch.rand((256, 1025, 938), generator=g, device=gpu) + 0.05
+    c = spectral_centroid(S=S, sr=16000)
+    b = spectral_bandwidth(S=S, sr=16000)
+    r = spectral_rolloff(S=S, sr=16000)
+    fl = spectral_flatness(S=S)
+    rows = [0, 100, 255]
+    Sc = S[rows].cpu().numpy()
+    np.testing.assert_allclose(c[rows].cpu().numpy(), orc.spectral_centroid(S=Sc, sr=16000), rtol=RTOL)
+    np.testing.assert_allclose(b[rows].cpu().numpy(), orc.spectral_bandwidth(S=Sc, sr=16000), rtol=5e-5)
+    np.testing.assert_allclose(fl[rows].cpu().numpy(), orc.spectral_flatness(S=Sc), rtol=5e-5)
+    assert np.abs(r[rows].cpu().numpy() - orc.spectral_rolloff(S=Sc, sr=16000)).max() <= 8000 / 1024 * 1.001
+    S4 = S * 4.0   # exact in float32
+    assert torch.allclose(spectral_centroid(S=S4, sr=16000), c, rtol=1e-6)
+    assert torch.equal(spectral_rolloff(S=S4, sr=16000), r)
+    assert torch.allclose(spectral_flatness(S=S4), fl, rtol=1e-5)
+    assert torch.allclose(spectral_bandwidth(S=S4, sr=16000), b, rtol=1e-6)
