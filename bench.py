@@ -15,6 +15,7 @@ Workloads (config.workload):
   resample    512 x 30 s @44.1 kHz -> 16 kHz, polyphase (up 160 / down 441)
   resample_fft 64 x 30 s @44.1 kHz -> 16 kHz, Fourier method (the reference's default)
   features    centroid + bandwidth + roll-off + flatness of a (512, 1025, 938) spectrogram
+  contrast    spectral contrast of the same spectrogram
 """
 
 from __future__ import annotations
@@ -111,6 +112,14 @@ def make_workload(name: str, clips: int, device, seed: int):
                 f"spectral centroid + bandwidth + roll-off + flatness of {clips} spectrograms "
                 "(1025 bins x 938 frames = 30 s @16 kHz, n_fft 2048 hop 512)",
                 "spectral features audio-hours/sec (4 statistics)")
+    if name == "contrast":
+        from mlx_audio_amd.primitives import spectral_contrast
+
+        S = torch.rand((clips, 1025, 938), generator=gen, device=device, dtype=torch.float32) + 0.05
+        abytes = clips * (1025 * 938 * 4 + 7 * 938 * 4)
+        return (lambda: spectral_contrast(S=S, sr=16000), clips * 30.0 / 3600.0, abytes,
+                f"spectral contrast (6 octave bands + residual, quantile 0.02) of {clips} "
+                "spectrograms (1025 bins x 938 frames)", "spectral contrast audio-hours/sec")
     raise SystemExit(f"unknown workload {name}")
 
 
@@ -120,6 +129,7 @@ KERNEL_OF = {
     "mfcc40": "fwd_kernel<2048, mel> (fused rFFT+mel+dB) followed by dct2_mfma_kernel",
     "htdemucs": "fwd_kernel<4096> then istft_kernel<4096> (fused inverse FFT + overlap-add)",
     "resample": "upfirdn_kernel (polyphase FIR, input span and phase table staged in LDS)",
+    "contrast": "spectral_contrast_kernel<16> (one thread per frame, sorted register arrays)",
     "features": "spectral_stat_kernel x 4 (one thread per frame, bins walked in order)",
     "resample_fft": "stockham_pass_kernel<16> x 22 + chirp / spectrum kernels (two chirp-z "
                     "convolutions per clip)",
@@ -218,7 +228,7 @@ def main() -> None:
               "torch.distributed.run for N>1", file=sys.stderr)
 
     default_clips = {"whisper128": 1024, "clap64": 1024, "mfcc40": 1024, "htdemucs": 32,
-                     "resample": 512, "resample_fft": 64, "features": 512}
+                     "resample": 512, "resample_fft": 64, "features": 512, "contrast": 512}
     clips = args.clips or default_clips.get(args.workload, 1024)
     step, units, abytes, desc, metric = make_workload(args.workload, clips, device, 1234 + rank)
 

@@ -247,6 +247,13 @@ int mia_resample_fft(const float* x, int64_t rows, int64_t n_in, int64_t n_out, 
 int mia_spectral_stat(const float* S, int64_t rows, int bins, int64_t frames, const float* freq,
                       const float* aux, int mode, float p, int norm, float fraction, float amin,
                       float power, float* out, void* stream);
+/* spectral_contrast (features.py:467-639; _ext.spectral_contrast): S as above; bands: device
+ * int32 (n_bands_out, 3) = {first bin, one past the last bin, values averaged at each end} per
+ * octave band, built by the caller from the bin frequencies as the reference does
+ * (features.py:566-599); max_quantile = the largest third entry (<= 64).  out: device
+ * (rows, n_bands_out, frames) = peak - valley (linear) or 10 log10 peak - 10 log10 valley. */
+int mia_spectral_contrast(const float* S, int64_t rows, int bins, int64_t frames, const int* bands,
+                          int n_bands_out, int max_quantile, int linear, float* out, void* stream);
 /* zero_crossing_rate (features.py:642-769): y device (rows, n); frames of frame_length every
  * hop_length samples after centre padding (zeros, or the edge sample if pad_edge) when
  * `center`; out device (rows, 1 + (n + 2*pad - frame_length) / hop_length) = sign changes

@@ -84,6 +84,69 @@ __global__ __launch_bounds__(256) void spectral_stat_kernel(
   out[g] = result;
 }
 
+// Spectral contrast: per frame and band, the mean of the nq smallest (valley) and of the nq
+// largest (peak) values among bins lo .. hi-1, or the mean of all of them when nq >= hi - lo.
+// band[k] = {lo, hi, nq}; an empty band (hi <= lo) yields peak = valley = 0.  One thread per
+// frame keeps the K smallest and K largest values seen so far in two sorted register arrays
+// (K >= every nq) and pushes each bin through both with K min/max pairs.
+template <int K>
+__global__ __launch_bounds__(256) void spectral_contrast_kernel(
+    const float* __restrict__ S, long long rows, int bins, long long F, const int* __restrict__ band,
+    int n_out, int linear, float* __restrict__ out) {
+  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= rows * F) return;
+  const long long row = g / F, f = g - row * F;
+  const float* __restrict__ col = S + row * bins * F + f;
+  for (int b = 0; b < n_out; ++b) {
+    const int lo = band[3 * b], hi = band[3 * b + 1], nq = band[3 * b + 2];
+    float peak = 0.0f, valley = 0.0f;
+    if (hi > lo) {
+      if (nq >= hi - lo) {
+        float sum = 0.0f;
+        for (int k = lo; k < hi; ++k) sum += col[(long long)k * F];
+        peak = valley = sum / (float)(hi - lo);
+      } else {
+        float small[K], large[K];
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+          small[i] = INFINITY;
+          large[i] = -INFINITY;
+        }
+#pragma unroll 2
+        for (int k = lo; k < hi; ++k) {
+          const float v = col[(long long)k * F];
+          float a = v, c = v;
+#pragma unroll
+          for (int i = 0; i < K; ++i) {
+            const float s0 = small[i], l0 = large[i];
+            small[i] = fminf(s0, a);
+            a = fmaxf(s0, a);
+            large[i] = fmaxf(l0, c);
+            c = fminf(l0, c);
+          }
+        }
+        float vs = 0.0f, ps = 0.0f;
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+          if (i < nq) {
+            vs += small[i];
+            ps += large[i];
+          }
+        }
+        valley = vs / (float)nq;
+        peak = ps / (float)nq;
+      }
+    }
+    float r;
+    if (linear) {
+      r = peak - valley;
+    } else {
+      r = 10.0f * log10f(fmaxf(peak, 1e-10f)) - 10.0f * log10f(fmaxf(valley, 1e-10f));
+    }
+    out[(row * n_out + b) * F + f] = r;
+  }
+}
+
 // out[row, frame] = (number of i in 1..L-1 with sign(x[i]) != sign(x[i-1])) / L over the
 // frame's L samples; sign = (x >= 0) or, with by_signbit, the IEEE sign bit.  Centre padding
 // (pad samples on both sides) by zeros or by the edge sample.
@@ -137,6 +200,38 @@ int mia_spectral_stat(const float* S, int64_t rows, int bins, int64_t frames, co
   hipLaunchKernelGGL(spectral_stat_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                      (hipStream_t)stream, S, (long long)rows, bins, (long long)frames, freq, aux,
                      mode, p, norm, fraction, amin, power_mode, power, out);
+  MIA_CHECK_HIP(hipGetLastError());
+  return MIA_OK;
+}
+
+int mia_spectral_contrast(const float* S, int64_t rows, int bins, int64_t frames, const int* bands,
+                          int n_bands_out, int max_quantile, int linear, float* out, void* stream) {
+  using namespace mia;
+  MIA_REQUIRE(rows >= 0 && bins >= 1 && frames >= 0 && n_bands_out >= 1,
+              "rows, bins, frames, n_bands_out must be >= 0, 1, 0, 1");
+  MIA_REQUIRE(max_quantile >= 1, "max_quantile must be >= 1");
+  if (rows == 0 || frames == 0) return MIA_OK;
+  MIA_REQUIRE(S && bands && out, "null pointer");
+  if (max_quantile > 64) {
+    set_error("spectral contrast: %d values per quantile exceed the supported 64", max_quantile);
+    return MIA_ERR_UNSUPPORTED;
+  }
+  const long long total = (long long)rows * frames;
+  if (total > 0x7fffffffLL * 256) {
+    set_error("%lld frames do not fit one launch (split the batch)", total);
+    return MIA_ERR_UNSUPPORTED;
+  }
+  const dim3 grid((unsigned)((total + 255) / 256));
+  hipStream_t s = (hipStream_t)stream;
+#define MIA_CONTRAST(KK)                                                                        \
+  hipLaunchKernelGGL((spectral_contrast_kernel<KK>), grid, dim3(256), 0, s, S, (long long)rows, \
+                     bins, (long long)frames, bands, n_bands_out, linear, out)
+  if (max_quantile <= 4) MIA_CONTRAST(4);
+  else if (max_quantile <= 8) MIA_CONTRAST(8);
+  else if (max_quantile <= 16) MIA_CONTRAST(16);
+  else if (max_quantile <= 32) MIA_CONTRAST(32);
+  else MIA_CONTRAST(64);
+#undef MIA_CONTRAST
   MIA_CHECK_HIP(hipGetLastError());
   return MIA_OK;
 }

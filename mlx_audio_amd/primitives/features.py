@@ -1,7 +1,6 @@
 """Spectral features on MI355X with the signatures of `mlx_audio.primitives.features`
 (reference python/mlx_audio/primitives/features.py): spectral_centroid, spectral_bandwidth,
-spectral_rolloff, spectral_flatness, zero_crossing_rate.  `spectral_contrast` (per-band
-quantiles, features.py:467-639) is not built and says so.
+spectral_rolloff, spectral_flatness, spectral_contrast, zero_crossing_rate.
 
 Each statistic is one kernel launch over the (rows, bins, frames) spectrogram; from a waveform
 the spectrogram comes from this package's `stft` + `magnitude`.
@@ -138,9 +137,70 @@ def spectral_flatness(y=None, S=None, n_fft: int = 2048, hop_length: int = 512, 
     return _stat(S, "flatness", amin=amin, power=power if from_y else 1.0)
 
 
-def spectral_contrast(*args, **kwargs):
-    """Per-band peak/valley contrast (reference features.py:467-639): not built."""
-    raise NotImplementedError("spectral_contrast is not built yet")
+def _contrast_bands(freq: np.ndarray, fmin: float, n_bands: int, quantile: float) -> np.ndarray:
+    """(n_bands + 1, 3) int32 rows {first bin, one past the last bin, values per quantile} of
+    the octave bands [0, fmin], [fmin, 2 fmin], ... (reference features.py:566-599): a band takes
+    the bins inside its edges plus the bin just below (not the first band), the last band runs to
+    the Nyquist bin, the count per quantile is taken before the top bin is dropped (every band
+    but the last drops it).  An empty band is {0, 0, 1}."""
+    octa = np.zeros(n_bands + 2)
+    octa[1:] = fmin * (2.0 ** np.arange(0, n_bands + 1))
+    rows = []
+    for k, (f_low, f_high) in enumerate(zip(octa[:-1], octa[1:])):
+        mask = np.logical_and(freq >= f_low, freq <= f_high)
+        idx = np.flatnonzero(mask)
+        if len(idx) == 0:
+            rows.append((0, 0, 1))
+            continue
+        if k > 0 and idx[0] > 0:
+            mask[idx[0] - 1] = True
+        if k == n_bands and idx[-1] + 1 < len(mask):
+            mask[idx[-1] + 1:] = True
+        sel = np.flatnonzero(mask)
+        if not np.array_equal(sel, np.arange(sel[0], sel[-1] + 1)):
+            raise NotImplementedError("spectral_contrast needs increasing bin frequencies")
+        nq = int(np.maximum(np.rint(quantile * len(sel)), 1))
+        hi = sel[-1] + 1
+        if k < n_bands and len(sel) > 1:
+            hi -= 1
+        rows.append((int(sel[0]), int(hi), nq))
+    return np.asarray(rows, dtype=np.int32)
+
+
+def spectral_contrast(y=None, sr: int = 22050, S=None, n_fft: int = 2048, hop_length: int = 512,
+                      win_length=None, window="hann", center: bool = True,
+                      pad_mode: str = "constant", freq=None, fmin: float = 200.0,
+                      n_bands: int = 6, quantile: float = 0.02,
+                      linear: bool = False) -> torch.Tensor:
+    """Peak-to-valley contrast per octave band and frame (reference features.py:467-639)."""
+    if n_bands <= 0:
+        raise ValueError(f"n_bands must be positive, got {n_bands}")
+    if quantile < 0.0:
+        raise ValueError(f"quantile must be >= 0.0, got {quantile}")
+    if quantile > 1.0:
+        raise ValueError(f"quantile must be <= 1.0, got {quantile}")
+    S = _compute_spectrogram(y, S, n_fft, hop_length, win_length, window, center, pad_mode)
+    if freq is None:
+        freq_np = _get_frequencies(sr, n_fft)
+    elif isinstance(freq, torch.Tensor):
+        freq_np = freq.detach().cpu().numpy().astype(np.float32)
+    else:
+        freq_np = np.asarray(freq, dtype=np.float32)
+    batched = S.dim() == 3
+    Sb = (S if batched else S[None]).contiguous()
+    rows, bins, frames = Sb.shape
+    if freq_np.shape != (bins,):
+        raise ValueError(f"freq has {freq_np.size} entries but the spectrogram has {bins} bins")
+    bands = _contrast_bands(freq_np, float(fmin), int(n_bands), float(quantile))
+    live = bands[:, 1] - bands[:, 0] > bands[:, 2]   # bands that actually select quantiles
+    max_q = int(bands[live, 2].max()) if live.any() else 1
+    bands_dev = torch.from_numpy(bands).to(Sb.device)
+    out = torch.empty((rows, n_bands + 1, frames), dtype=torch.float32, device=Sb.device)
+    with torch.cuda.device(Sb.device):
+        _lib.check(_lib.lib().mia_spectral_contrast(
+            Sb.data_ptr(), rows, bins, frames, bands_dev.data_ptr(), n_bands + 1, max_q,
+            int(bool(linear)), out.data_ptr(), stream_ptr(Sb.device)))
+    return out if batched else out[0]
 
 
 def zero_crossing_rate(y, frame_length: int = 2048, hop_length: int = 512, center: bool = True,

@@ -124,3 +124,70 @@ def zero_crossing_rate(y, frame_length=2048, hop_length=512, center=True, pad_mo
     cross = sign[..., 1:] != sign[..., :-1]
     zcr = (cross.sum(axis=-1).astype(np.float32) / np.float32(frame_length))[:, None, :]
     return zcr[0] if is_1d else zcr
+
+
+def contrast_bands(freq, fmin, n_bands, quantile):
+    """Band table of spectral_contrast (features.py:566-599): per octave band the boolean mask
+    of its bins (after the neighbour-bin and last-band extensions), whether the last masked
+    bin is dropped, and the number of values averaged at each end."""
+    freq = np.asarray(freq)
+    octa = np.zeros(n_bands + 2)
+    octa[1:] = fmin * (2.0 ** np.arange(0, n_bands + 1))
+    bands = []
+    for k, (f_low, f_high) in enumerate(zip(octa[:-1], octa[1:])):
+        mask = np.logical_and(freq >= f_low, freq <= f_high)
+        idx = np.flatnonzero(mask)
+        if len(idx) == 0:
+            bands.append(None)
+            continue
+        if k > 0 and idx[0] > 0:
+            mask[idx[0] - 1] = True
+        if k == n_bands and idx[-1] + 1 < len(mask):
+            mask[idx[-1] + 1:] = True
+        n_quantile = int(np.maximum(np.rint(quantile * np.sum(mask)), 1))
+        sel = np.flatnonzero(mask)
+        if k < n_bands and len(sel) > 1:
+            sel = sel[:-1]
+        bands.append((sel, n_quantile))
+    return bands
+
+
+def spectral_contrast(y=None, sr=22050, S=None, n_fft=2048, hop_length=512, win_length=None,
+                      window="hann", center=True, pad_mode="constant", freq=None, fmin=200.0,
+                      n_bands=6, quantile=0.02, linear=False):
+    """features.py:467-639 (the NumPy branch, which the reference describes as librosa's exact
+    algorithm)."""
+    if n_bands <= 0:
+        raise ValueError(f"n_bands must be positive, got {n_bands}")
+    if quantile < 0.0:
+        raise ValueError(f"quantile must be >= 0.0, got {quantile}")
+    if quantile > 1.0:
+        raise ValueError(f"quantile must be <= 1.0, got {quantile}")
+    S = compute_spectrogram(y, S, n_fft, hop_length, win_length, window, center, pad_mode)
+    freq = get_frequencies(sr, n_fft) if freq is None else np.asarray(freq, np.float32)
+    S, batched = _batched(S)
+    B, _, F = S.shape
+    valley = np.zeros((B, n_bands + 1, F), np.float32)
+    peak = np.zeros_like(valley)
+    for k, band in enumerate(contrast_bands(freq, fmin, n_bands, quantile)):
+        if band is None:
+            continue
+        sel, nq = band
+        sub = S[:, sel, :]
+        n_sub = sub.shape[1]
+        if n_sub == 0:
+            continue
+        if nq < n_sub:
+            bottom = np.partition(sub, nq - 1, axis=1)
+            valley[:, k, :] = np.mean(bottom[:, :nq, :], axis=1)
+            top = np.partition(sub, n_sub - nq, axis=1)
+            peak[:, k, :] = np.mean(top[:, n_sub - nq:, :], axis=1)
+        else:
+            valley[:, k, :] = np.mean(sub, axis=1)
+            peak[:, k, :] = np.mean(sub, axis=1)
+    if linear:
+        out = peak - valley
+    else:
+        out = 10.0 * np.log10(np.maximum(peak, 1e-10) / 1.0) - 10.0 * np.log10(np.maximum(valley, 1e-10) / 1.0)
+    out = out.astype(np.float32)
+    return out if batched else out[0]

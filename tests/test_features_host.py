@@ -75,8 +75,10 @@ def test_argument_checks_follow_the_reference():
         zero_crossing_rate(y, hop_length=0)
     with pytest.raises(ValueError, match="Unknown pad_mode: 'reflect'"):
         zero_crossing_rate(y, pad_mode="reflect")
-    with pytest.raises(NotImplementedError):
-        spectral_contrast(y)
+    with pytest.raises(ValueError, match="n_bands must be positive"):
+        spectral_contrast(y, n_bands=0)
+    with pytest.raises(ValueError, match="quantile must be <= 1.0"):
+        spectral_contrast(y, quantile=1.5)
     with pytest.raises(ValueError, match="roll_percent must be <= 1.0"):
         orc.spectral_rolloff(y, roll_percent=1.5)
     with pytest.raises(ValueError, match="Either y"):
@@ -92,3 +94,31 @@ def test_either_y_or_S_is_required():
     else:
         with pytest.raises((ValueError, RuntimeError)):
             spectral_centroid()
+
+
+def test_contrast_band_table_and_closed_form():
+    import importlib
+
+    mod = importlib.import_module("mlx_audio_amd.primitives.features")
+    for sr, n_fft, fmin, n_bands, q in [(22050, 2048, 200.0, 6, 0.02), (16000, 512, 100.0, 5, 0.1),
+                                        (44100, 4096, 200.0, 6, 0.02), (8000, 256, 200.0, 6, 0.5)]:
+        freq = orc.get_frequencies(sr, n_fft)
+        table = mod._contrast_bands(freq, fmin, n_bands, q)
+        want = orc.contrast_bands(freq, fmin, n_bands, q)
+        assert table.shape == (n_bands + 1, 3)
+        for row, band in zip(table, want):
+            if band is None:
+                assert row[1] <= row[0]
+            else:
+                sel, nq = band
+                np.testing.assert_array_equal(np.arange(row[0], row[1]), sel)
+                assert row[2] == nq
+    # two levels per band: peak = the high level, valley = the low one
+    freq = orc.get_frequencies(22050, 2048)
+    S = np.full((1025, 3), 0.01, np.float32)
+    S[::2] = 1.0
+    c = orc.spectral_contrast(S=S, sr=22050, quantile=0.1)
+    assert c.shape == (7, 3)
+    np.testing.assert_allclose(c, 20.0, atol=1e-4)          # 10 log10(1 / 0.01)
+    np.testing.assert_allclose(orc.spectral_contrast(S=S, sr=22050, quantile=0.1, linear=True), 0.99,
+                               atol=1e-6)

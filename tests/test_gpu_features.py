@@ -10,8 +10,8 @@ import torch
 
 import oracle.features as orc
 from mlx_audio_amd import _lib
-from mlx_audio_amd.primitives import (spectral_bandwidth, spectral_centroid, spectral_flatness,
-                                      spectral_rolloff, zero_crossing_rate)
+from mlx_audio_amd.primitives import (spectral_bandwidth, spectral_centroid, spectral_contrast,
+                                      spectral_flatness, spectral_rolloff, zero_crossing_rate)
 
 pytestmark = pytest.mark.gpu
 
@@ -105,6 +105,36 @@ def test_zero_crossing_rate_is_exact(gpu, frame_length, hop):
                 np.testing.assert_array_equal(got.cpu().numpy(), want)
     np.testing.assert_array_equal(zero_crossing_rate(_dev(y[2], gpu), frame_length, hop).cpu().numpy(),
                                   orc.zero_crossing_rate(y[2], frame_length, hop))
+
+
+@pytest.mark.parametrize("sr,n_fft,kw", [
+    (22050, 2048, {}), (22050, 2048, {"linear": True}), (16000, 512, {"fmin": 100.0, "n_bands": 5, "quantile": 0.1}),
+    (44100, 4096, {}), (8000, 256, {"quantile": 0.5}), (22050, 1024, {"quantile": 1.0}),
+    (22050, 2048, {"quantile": 0.0}), (22050, 2048, {"quantile": 0.12}), (48000, 1024, {"fmin": 4000.0, "n_bands": 4}),
+])
+def test_spectral_contrast(gpu, sr, n_fft, kw):
+    """Order statistics: the same values are selected, only the order of the few additions in the
+    means differs (1e-6 relative on the linear values; 2e-5 dB)."""
+    rng = np.random.default_rng(n_fft + sr)
+    S = _spec(rng, (2, n_fft // 2 + 1, 37))
+    got = spectral_contrast(S=_dev(S, gpu), sr=sr, n_fft=n_fft, **kw).cpu().numpy()
+    want = orc.spectral_contrast(S=S, sr=sr, n_fft=n_fft, **kw)
+    assert got.shape == want.shape == (2, kw.get("n_bands", 6) + 1, 37)
+    np.testing.assert_allclose(got, want, rtol=2e-6, atol=3e-5)
+    one = spectral_contrast(S=_dev(S[0], gpu), sr=sr, n_fft=n_fft, **kw).cpu().numpy()
+    np.testing.assert_allclose(one, want[0], rtol=2e-6, atol=3e-5)
+
+
+def test_spectral_contrast_from_a_waveform_and_limits(gpu):
+    rng = np.random.default_rng(5)
+    y = rng.standard_normal((2, 22050)).astype(np.float32)
+    got = spectral_contrast(_dev(y, gpu), sr=22050).cpu().numpy()
+    want = orc.spectral_contrast(y, sr=22050)
+    assert got.shape == want.shape
+    np.testing.assert_allclose(got, want, rtol=1e-4, atol=2e-3)
+    S = _spec(rng, (1, 4097, 5))   # 0.2 of the 2800-bin top band is far more than 64 values
+    with pytest.raises(NotImplementedError, match="exceed the supported 64"):
+        spectral_contrast(S=_dev(S, gpu), sr=44100, n_fft=8192, quantile=0.2)
 
 
 def test_short_signals_and_c_abi_checks(gpu):
