@@ -16,6 +16,7 @@ Workloads (config.workload):
   resample_fft 64 x 30 s @44.1 kHz -> 16 kHz, Fourier method (the reference's default)
   features    centroid + bandwidth + roll-off + flatness of a (512, 1025, 938) spectrogram
   contrast    spectral contrast of the same spectrogram
+  onset       onset strength of 4096 mel spectrograms (128 x 938)
 """
 
 from __future__ import annotations
@@ -120,6 +121,14 @@ def make_workload(name: str, clips: int, device, seed: int):
         return (lambda: spectral_contrast(S=S, sr=16000), clips * 30.0 / 3600.0, abytes,
                 f"spectral contrast (6 octave bands + residual, quantile 0.02) of {clips} "
                 "spectrograms (1025 bins x 938 frames)", "spectral contrast audio-hours/sec")
+    if name == "onset":
+        from mlx_audio_amd.primitives import onset_strength
+
+        S = torch.rand((clips, 128, 938), generator=gen, device=device, dtype=torch.float32)
+        abytes = clips * (128 * 938 * 4 + 938 * 4)
+        return (lambda: onset_strength(S=S), clips * 30.0 / 3600.0, abytes,
+                f"onset strength (log1p flux, mean over 128 mel bands) of {clips} mel "
+                "spectrograms (128 x 938 = 30 s @16 kHz)", "onset strength audio-hours/sec")
     raise SystemExit(f"unknown workload {name}")
 
 
@@ -130,6 +139,7 @@ KERNEL_OF = {
     "htdemucs": "fwd_kernel<4096> then istft_kernel<4096> (fused inverse FFT + overlap-add)",
     "resample": "upfirdn_kernel (polyphase FIR, input span and phase table staged in LDS)",
     "contrast": "spectral_contrast_kernel<16> (one thread per frame, sorted register arrays)",
+    "onset": "onset_flux_kernel (one thread per frame, bands walked in order)",
     "features": "spectral_stat_kernel x 4 (one thread per frame, bins walked in order)",
     "resample_fft": "stockham_pass_kernel<16> x 22 + chirp / spectrum kernels (two chirp-z "
                     "convolutions per clip)",
@@ -228,7 +238,7 @@ def main() -> None:
               "torch.distributed.run for N>1", file=sys.stderr)
 
     default_clips = {"whisper128": 1024, "clap64": 1024, "mfcc40": 1024, "htdemucs": 32,
-                     "resample": 512, "resample_fft": 64, "features": 512, "contrast": 512}
+                     "resample": 512, "resample_fft": 64, "features": 512, "contrast": 512, "onset": 4096}
     clips = args.clips or default_clips.get(args.workload, 1024)
     step, units, abytes, desc, metric = make_workload(args.workload, clips, device, 1234 + rank)
 

@@ -262,6 +262,23 @@ int mia_spectral_contrast(const float* S, int64_t rows, int bins, int64_t frames
 int mia_zero_crossing_rate(const float* y, int64_t rows, int64_t n, int frame_length, int hop_length,
                            int center, int pad_edge, int by_signbit, float* out, void* stream);
 
+/* ---- onset strength (primitives/onset.py) -------------------------------------------
+ * onset_strength's spectral flux (onset.py:125-147): S device (rows, bands, frames), frames
+ * contiguous; out device (rows, frames): 0 for the first `lag` frames (the reference pads
+ * them back, :170-171), else the mean / max / median over the bands of
+ * max(log1p(1e4 S[m,t]) - log1p(1e4 S[m,t-lag]), 0). */
+#define MIA_AGG_MEAN 0
+#define MIA_AGG_MAX 1
+#define MIA_AGG_MEDIAN 2
+int mia_onset_flux(const float* S, int64_t rows, int bands, int64_t frames, int lag, int aggregate,
+                   float* out, void* stream);
+/* The envelope filters of onset_strength (onset.py:150-166, scipy.ndimage.maximum_filter1d /
+ * uniform_filter1d with their default reflecting boundary) over rows of n samples (row strides
+ * in elements; src and dst must not overlap): mode 0 = maximum over the window
+ * [i - size/2, i + (size-1)/2]; mode 1 = max(src[i] - mean over that window, 0). */
+int mia_envelope_filter(const float* src, int64_t rows, int64_t n, int64_t src_stride, int size,
+                        int mode, float* dst, int64_t dst_stride, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

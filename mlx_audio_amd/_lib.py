@@ -92,6 +92,9 @@ SIGNATURES = {
                                       c_int, c_void_p, c_void_p]),
     "mia_zero_crossing_rate": (c_int, [c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_int,
                                        c_int, c_void_p, c_void_p]),
+    "mia_onset_flux": (c_int, [c_void_p, c_int64, c_int, c_int64, c_int, c_int, c_void_p, c_void_p]),
+    "mia_envelope_filter": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_void_p,
+                                    c_int64, c_void_p]),
     "mia_resample_fft_table_bytes": (c_size_t, [c_int64, c_int64]),
     "mia_resample_fft_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int64]),
     "mia_resample_fft_tables": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -7,6 +7,7 @@ from .features import (spectral_bandwidth, spectral_centroid, spectral_contrast,
                        spectral_flatness, spectral_rolloff, zero_crossing_rate)
 from .mel import hz_to_mel, mel_filterbank, mel_to_hz, melspectrogram
 from .mfcc import dct, mfcc
+from .onset import onset_detect, onset_strength, onset_strength_multi
 from .resample import resample, resample_poly
 from .stft import check_nola, istft, magnitude, phase, stft
 from .windows import get_window
@@ -20,4 +21,5 @@ __all__ = [
     "resample", "resample_poly",
     "spectral_centroid", "spectral_bandwidth", "spectral_rolloff", "spectral_flatness",
     "spectral_contrast", "zero_crossing_rate",
+    "onset_strength", "onset_detect", "onset_strength_multi",
 ]
