@@ -17,6 +17,7 @@ Workloads (config.workload):
   features    centroid + bandwidth + roll-off + flatness of a (512, 1025, 938) spectrogram
   contrast    spectral contrast of the same spectrogram
   onset       onset strength of 4096 mel spectrograms (128 x 938)
+  griffinlim  8 Griffin-Lim iterations on 64 x 10 s @22.05 kHz, n_fft 2048 / hop 512
 """
 
 from __future__ import annotations
@@ -129,6 +130,21 @@ def make_workload(name: str, clips: int, device, seed: int):
         return (lambda: onset_strength(S=S), clips * 30.0 / 3600.0, abytes,
                 f"onset strength (log1p flux, mean over 128 mel bands) of {clips} mel "
                 "spectrograms (128 x 938 = 30 s @16 kHz)", "onset strength audio-hours/sec")
+    if name == "griffinlim":
+        from mlx_audio_amd.primitives import griffinlim, magnitude
+
+        T = 220500
+        y = torch.randn((clips, T), generator=gen, device=device, dtype=torch.float32)
+        S = magnitude(stft(y, n_fft=2048, hop_length=512))
+        bins, frames, n_iter = S.shape[1], S.shape[2], 8
+        # per iteration the state that has to stream through once even if inverse STFT, forward
+        # STFT and update were one pass: spectrum in and out (8 + 8 B per bin), target magnitude
+        # (4 B), previous estimate in and out (8 + 8 B); plus the final signal
+        abytes = clips * (n_iter * 36 * bins * frames + 4 * T)
+        return (lambda: griffinlim(S, n_iter=n_iter, init="zeros"), clips * 10.0 / 3600.0, abytes,
+                f"Griffin-Lim, {n_iter} iterations, {clips} x 10 s @22.05 kHz, n_fft 2048 hop 512 "
+                "(zero initial phase; per iteration: fused iSTFT, fused STFT, phase update)",
+                "Griffin-Lim audio-hours/sec (8 iterations)")
     raise SystemExit(f"unknown workload {name}")
 
 
@@ -139,7 +155,8 @@ KERNEL_OF = {
     "htdemucs": "fwd_kernel<4096> then istft_kernel<4096> (fused inverse FFT + overlap-add)",
     "resample": "upfirdn_kernel (polyphase FIR, input span and phase table staged in LDS)",
     "contrast": "spectral_contrast_kernel<16> (one thread per frame, sorted register arrays)",
-    "onset": "onset_flux_kernel (one thread per frame, bands walked in order)",
+    "griffinlim": "per iteration istft_kernel<2048> + fwd_kernel<2048> + griffinlim_update_kernel",
+    "onset": "onset_flux_shift_kernel (a wave per 64 frames, lagged values by lane shift)",
     "features": "spectral_stat_kernel x 4 (one thread per frame, bins walked in order)",
     "resample_fft": "stockham_pass_kernel<16> x 22 + chirp / spectrum kernels (two chirp-z "
                     "convolutions per clip)",
@@ -238,7 +255,7 @@ def main() -> None:
               "torch.distributed.run for N>1", file=sys.stderr)
 
     default_clips = {"whisper128": 1024, "clap64": 1024, "mfcc40": 1024, "htdemucs": 32,
-                     "resample": 512, "resample_fft": 64, "features": 512, "contrast": 512, "onset": 4096}
+                     "resample": 512, "resample_fft": 64, "features": 512, "contrast": 512, "onset": 4096, "griffinlim": 64}
     clips = args.clips or default_clips.get(args.workload, 1024)
     step, units, abytes, desc, metric = make_workload(args.workload, clips, device, 1234 + rank)
 

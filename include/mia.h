@@ -279,6 +279,15 @@ int mia_onset_flux(const float* S, int64_t rows, int bands, int64_t frames, int 
 int mia_envelope_filter(const float* src, int64_t rows, int64_t n, int64_t src_stride, int size,
                         int mode, float* dst, int64_t dst_stride, void* stream);
 
+/* ---- Griffin-Lim (primitives/griffinlim.py) -----------------------------------------
+ * out[i] = mag[i] * exp(i angle[i]) (griffinlim.py:121, 247): n complex64 values. */
+int mia_polar(const float* mag, const float* angle, int64_t n, void* out, void* stream);
+/* One phase update (griffinlim.py:165-176): with u = c_new / |c_new| (1 where c_new = 0),
+ * r = mag * u;  rebuilt = r + momentum * (r - tprev) (r itself if momentum == 0);  tprev = r.
+ * c_new, tprev, rebuilt: n complex64 values, mag: n floats, all in the same element order. */
+int mia_griffinlim_update(const void* c_new, const float* mag, void* tprev, void* rebuilt,
+                          int64_t n, float momentum, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -92,6 +92,9 @@ SIGNATURES = {
                                       c_int, c_void_p, c_void_p]),
     "mia_zero_crossing_rate": (c_int, [c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_int,
                                        c_int, c_void_p, c_void_p]),
+    "mia_polar": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "mia_griffinlim_update": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float,
+                                      c_void_p]),
     "mia_onset_flux": (c_int, [c_void_p, c_int64, c_int, c_int64, c_int, c_int, c_void_p, c_void_p]),
     "mia_envelope_filter": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_void_p,
                                     c_int64, c_void_p]),
