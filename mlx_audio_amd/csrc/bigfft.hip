@@ -15,6 +15,11 @@
 #include "fft_engine.h"
 #include "mia_internal.h"
 
+// Butterfly sizes tried, largest first, when a length is split into passes.
+#ifndef MIA_RADIX_CANDIDATES
+#define MIA_RADIX_CANDIDATES 36, 35, 32, 30, 28, 27, 25, 24, 21, 20, 18, 16, 15, 14, 12, 10, 9, 8, 7, 6, 5, 4, 3, 2
+#endif
+
 namespace mia {
 
 __device__ __forceinline__ float2 cmulf(float2 a, float2 b) {
@@ -163,17 +168,6 @@ __global__ __launch_bounds__(256) void stockham_any_kernel(const float2* __restr
   const unsigned m = j % Ns;
   double s1 = 0.0, c1 = 1.0;
   if (Ns > 1) sincospi(-2.0 * (double)m / ((double)Ns * (double)R), &s1, &c1);
-  float2 w[R];
-  {
-    double wr = c1, wi = s1;
-#pragma unroll
-    for (int r = 1; r < R; ++r) {
-      w[r] = {(float)wr, (float)wi};
-      const double nr = wr * c1 - wi * s1;
-      wi = wr * s1 + wi * c1;
-      wr = nr;
-    }
-  }
   const size_t base = (size_t)(j - m) * R + m;
   for (long long row = blockIdx.y; row < rows; row += gridDim.y) {
     const float2* __restrict__ src = in + (size_t)row * L + j;
@@ -181,8 +175,14 @@ __global__ __launch_bounds__(256) void stockham_any_kernel(const float2* __restr
 #pragma unroll
     for (int r = 0; r < R; ++r) v[r] = src[(size_t)r * Lr];
     if (Ns > 1) {
+      double wr = c1, wi = s1;
 #pragma unroll
-      for (int r = 1; r < R; ++r) v[r] = cmulf(v[r], w[r]);
+      for (int r = 1; r < R; ++r) {
+        v[r] = cmulf(v[r], float2{(float)wr, (float)wi});
+        const double nr = wr * c1 - wi * s1;
+        wi = wr * s1 + wi * c1;
+        wr = nr;
+      }
     }
     Dft<R>::run(v);
     float2* __restrict__ dst = out + (size_t)row * L + base;
@@ -244,25 +244,41 @@ __global__ void unpack_real_kernel(const float2* __restrict__ F, long long total
   y[g] = {f.x * scale, -f.y * scale};
 }
 
-// Radices of a mixed-radix plan for length L, largest butterflies first; 0 if L has a prime
-// factor other than 2, 3, 5, 7.
-static int plan_radices(long long L, int* radices) {
-  static const int cand[] = {16, 15, 12, 10, 8, 7, 6, 5, 4, 3, 2};
-  int n = 0;
-  while (L > 1) {
-    bool found = false;
-    for (int c : cand) {
-      if (L % c == 0) {
-        radices[n++] = c;
-        L /= c;
-        found = true;
-        break;
-      }
+// Radices of a mixed-radix plan for length L: the fewest passes the available butterflies
+// allow and, among those, the smallest butterflies (registers); largest first.  Returns the
+// number of passes, 0 if L has a prime factor other than 2, 3, 5, 7.
+static int plan_search(long long L, const int* cand, int n_cand, int first, int depth, int limit,
+                       int* cur, int* best, int* best_sum, int sum) {
+  if (L == 1) {
+    if (depth < limit || (depth == limit && sum < *best_sum)) {
+      for (int i = 0; i < depth; ++i) best[i] = cur[i];
+      *best_sum = sum;
+      return depth;
     }
-    if (!found) return 0;
-    if (n >= 32) return 0;
+    return limit;
   }
-  return n;
+  if (depth >= limit) return limit;  // cannot beat the best plan found so far
+  for (int i = first; i < n_cand; ++i) {
+    if (L % cand[i]) continue;
+    cur[depth] = cand[i];
+    limit = plan_search(L / cand[i], cand, n_cand, i, depth + 1, limit, cur, best, best_sum,
+                        sum + cand[i]);
+  }
+  return limit;
+}
+static int plan_radices(long long L, int* radices) {
+  static const int cand[] = {MIA_RADIX_CANDIDATES};
+  const int n_cand = (int)(sizeof(cand) / sizeof(cand[0]));
+  long long rest = L;
+  for (int p : {2, 3, 5, 7}) {
+    while (rest % p == 0) rest /= p;
+  }
+  if (rest != 1 || L < 2) return 0;
+  int cur[32], best_sum = 1 << 30;
+  int limit = 28;  // 2^27 = 28 passes of radix 2 at worst
+  for (int i = 0; i < 32; ++i) radices[i] = 0;
+  limit = plan_search(L, cand, n_cand, 0, 0, limit + 1, cur, radices, &best_sum, 0);
+  return radices[0] ? limit : 0;
 }
 static bool direct_ok(long long n_in, long long n_out) {
   int r[32];
@@ -292,8 +308,10 @@ static int fft_any(const float2* in, float2* bufA, float2* bufB, long long L, lo
 #define MIA_PASS(RR) \
   case RR: hipLaunchKernelGGL((stockham_any_kernel<RR>), grid, dim3(256), 0, s, src, dst, (unsigned)L, Ns, rows); break;
     switch (R) {
-      MIA_PASS(16) MIA_PASS(15) MIA_PASS(12) MIA_PASS(10) MIA_PASS(8) MIA_PASS(7)
-      MIA_PASS(6) MIA_PASS(5) MIA_PASS(4) MIA_PASS(3) MIA_PASS(2)
+      MIA_PASS(36) MIA_PASS(35) MIA_PASS(32) MIA_PASS(30) MIA_PASS(28) MIA_PASS(27) MIA_PASS(25)
+      MIA_PASS(24) MIA_PASS(21) MIA_PASS(20) MIA_PASS(18)
+      MIA_PASS(16) MIA_PASS(15) MIA_PASS(14) MIA_PASS(12) MIA_PASS(10) MIA_PASS(9) MIA_PASS(8)
+      MIA_PASS(7) MIA_PASS(6) MIA_PASS(5) MIA_PASS(4) MIA_PASS(3) MIA_PASS(2)
       default: break;
     }
 #undef MIA_PASS

@@ -250,6 +250,16 @@ template <> struct Dft<16> : DftCT<4, 4> {};
 template <> struct Dft<20> : DftCT<4, 5> {};
 template <> struct Dft<25> : DftCT<5, 5> {};
 template <> struct Dft<32> : DftCT<4, 8> {};
+template <> struct Dft<9> : DftCT<3, 3> {};
+template <> struct Dft<14> : DftCT<2, 7> {};
+template <> struct Dft<18> : DftCT<2, 9> {};
+template <> struct Dft<21> : DftCT<3, 7> {};
+template <> struct Dft<24> : DftCT<4, 6> {};
+template <> struct Dft<27> : DftCT<3, 9> {};
+template <> struct Dft<28> : DftCT<4, 7> {};
+template <> struct Dft<30> : DftCT<5, 6> {};
+template <> struct Dft<35> : DftCT<5, 7> {};
+template <> struct Dft<36> : DftCT<4, 9> {};
 
 // ----------------------------------------------------------------------------
 // Real-input DFTs.  rdft5: 5 real samples -> X[0] (real), X[1], X[2]
