@@ -18,6 +18,7 @@ Workloads (config.workload):
   contrast    spectral contrast of the same spectrogram
   onset       onset strength of 4096 mel spectrograms (128 x 938)
   griffinlim  8 Griffin-Lim iterations on 64 x 10 s @22.05 kHz, n_fft 2048 / hop 512
+  spectral_gate  spectral gating of 64 x 10 s @22.05 kHz
 """
 
 from __future__ import annotations
@@ -145,6 +146,17 @@ def make_workload(name: str, clips: int, device, seed: int):
                 f"Griffin-Lim, {n_iter} iterations, {clips} x 10 s @22.05 kHz, n_fft 2048 hop 512 "
                 "(zero initial phase; per iteration: fused iSTFT, fused STFT, phase update)",
                 "Griffin-Lim audio-hours/sec (8 iterations)")
+    if name == "spectral_gate":
+        from mlx_audio_amd.primitives import spectral_gate
+
+        T = 220500
+        y = 0.05 * torch.randn((clips, T), generator=gen, device=device, dtype=torch.float32)
+        tt = torch.arange(T, device=device) / 22050.0
+        y = y + torch.sin(2 * 3.141592653589793 * 440 * tt) * (tt > 2.0)
+        abytes = clips * 2 * T * 4   # the waveform in, the waveform out
+        return (lambda: spectral_gate(y), clips * 10.0 / 3600.0, abytes,
+                f"spectral gating (stationary noise estimate, default smoothing), {clips} x 10 s "
+                "@22.05 kHz, n_fft 2048 hop 512", "spectral gate audio-hours/sec")
     raise SystemExit(f"unknown workload {name}")
 
 
@@ -155,6 +167,7 @@ KERNEL_OF = {
     "htdemucs": "fwd_kernel<4096> then istft_kernel<4096> (fused inverse FFT + overlap-add)",
     "resample": "upfirdn_kernel (polyphase FIR, input span and phase table staged in LDS)",
     "contrast": "spectral_contrast_kernel<16> (one thread per frame, sorted register arrays)",
+    "spectral_gate": "fwd_kernel<2048> + magnitude/phase + 9 mask kernels + polar + istft_kernel<2048>",
     "griffinlim": "per iteration istft_kernel<2048> + fwd_kernel<2048> + griffinlim_update_kernel",
     "onset": "onset_flux_shift_kernel (a wave per 64 frames, lagged values by lane shift)",
     "features": "spectral_stat_kernel x 4 (one thread per frame, bins walked in order)",
@@ -255,7 +268,7 @@ def main() -> None:
               "torch.distributed.run for N>1", file=sys.stderr)
 
     default_clips = {"whisper128": 1024, "clap64": 1024, "mfcc40": 1024, "htdemucs": 32,
-                     "resample": 512, "resample_fft": 64, "features": 512, "contrast": 512, "onset": 4096, "griffinlim": 64}
+                     "resample": 512, "resample_fft": 64, "features": 512, "contrast": 512, "onset": 4096, "griffinlim": 64, "spectral_gate": 64}
     clips = args.clips or default_clips.get(args.workload, 1024)
     step, units, abytes, desc, metric = make_workload(args.workload, clips, device, 1234 + rank)
 

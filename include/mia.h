@@ -288,6 +288,32 @@ int mia_polar(const float* mag, const float* angle, int64_t n, void* out, void* 
 int mia_griffinlim_update(const void* c_new, const float* mag, void* tprev, void* rebuilt,
                           int64_t n, float momentum, void* stream);
 
+/* ---- spectral gating (primitives/spectral_gate.py) ------------------------------------
+ * The host arithmetic the reference runs in NumPy / scipy.ndimage between its STFT and inverse
+ * STFT, on magnitudes (rows, bins, frames), frames contiguous.
+ * mia_frame_energy: mean over bins of mag^2 per frame (spectral_gate.py:162).
+ * mia_noise_threshold: per (row, bin) mean + n_std * population std over the frames listed in
+ *   frame_idx (rows, n_selected) int32, or over all frames if frame_idx is null
+ *   (spectral_gate.py:151-154, 168-177).
+ * mia_time_min_filter: scipy.ndimage.minimum_filter1d(x, size, axis=-1, mode="nearest") over
+ *   rows of n values (spectral_gate.py:183-186, 322-324).
+ * mia_box_filter: scipy.ndimage.uniform_filter1d(x, size, mode="nearest") along the middle axis
+ *   of x viewed as (outer, n, inner); two calls make the reference's uniform_filter with size
+ *   (1, a, b) (spectral_gate.py:207-212, 336).
+ * mia_gate_mask: clip((mag - thr * gain) / (mag + 1e-8), 0, 1) (spectral_gate.py:190-196); thr is
+ *   (rows, bins, frames), or with per_bin (rows_thr, bins) with rows_thr = rows or 1.
+ * mia_mask_op: op 0: 1 - p * (1 - a) (spectral_gate.py:215); op 1: a * b (:218). */
+int mia_frame_energy(const float* mag, int64_t rows, int bins, int64_t frames, float* energy,
+                     void* stream);
+int mia_noise_threshold(const float* mag, int64_t rows, int bins, int64_t frames, const int* frame_idx,
+                        int n_selected, float n_std, float* thr, void* stream);
+int mia_time_min_filter(const float* x, int64_t rows, int64_t n, int size, float* out, void* stream);
+int mia_box_filter(const float* x, int64_t outer, int64_t n, int64_t inner, int size, float* out,
+                   void* stream);
+int mia_gate_mask(const float* mag, const float* thr, int64_t rows, int bins, int64_t frames,
+                  int per_bin, int64_t rows_thr, float gain, float* mask, void* stream);
+int mia_mask_op(const float* a, const float* b, int64_t n, int op, float p, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -92,6 +92,14 @@ SIGNATURES = {
                                       c_int, c_void_p, c_void_p]),
     "mia_zero_crossing_rate": (c_int, [c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_int,
                                        c_int, c_void_p, c_void_p]),
+    "mia_frame_energy": (c_int, [c_void_p, c_int64, c_int, c_int64, c_void_p, c_void_p]),
+    "mia_noise_threshold": (c_int, [c_void_p, c_int64, c_int, c_int64, c_void_p, c_int, c_float,
+                                    c_void_p, c_void_p]),
+    "mia_time_min_filter": (c_int, [c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p]),
+    "mia_box_filter": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_void_p]),
+    "mia_gate_mask": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int64, c_int, c_int64, c_float,
+                              c_void_p, c_void_p]),
+    "mia_mask_op": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p, c_void_p]),
     "mia_polar": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "mia_griffinlim_update": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float,
                                       c_void_p]),

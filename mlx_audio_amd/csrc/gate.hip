@@ -1,0 +1,201 @@
+// Spectral gating: the steps between the forward and the inverse STFT of a noise gate, on
+// magnitudes laid out (rows, bins, frames) with frames contiguous.  Every kernel is one thread
+// per output element (or per frame / per bin for the reductions) with consecutive lanes on
+// consecutive frames, so loads are coalesced row segments; windows are a handful of samples.
+#include "mia_internal.h"
+
+namespace mia {
+
+constexpr float kGateEps = 1e-8f;  // the reference's DIVISION_EPSILON
+
+// energy[row, f] = mean over bins of mag^2
+__global__ __launch_bounds__(256) void frame_energy_kernel(const float* __restrict__ mag,
+                                                           long long rows, int bins, long long F,
+                                                           float* __restrict__ energy) {
+  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= rows * F) return;
+  const long long row = g / F, f = g - row * F;
+  const float* __restrict__ col = mag + row * bins * F + f;
+  float acc = 0.0f;
+#pragma unroll 8
+  for (int k = 0; k < bins; ++k) {
+    const float v = col[(long long)k * F];
+    acc += v * v;
+  }
+  energy[g] = acc / (float)bins;
+}
+
+// thr[row, bin] = mean + n_std * std (population) of mag[row, bin, idx[row, q]], q < n_sel;
+// idx == nullptr selects every frame.
+__global__ __launch_bounds__(256) void noise_threshold_kernel(const float* __restrict__ mag,
+                                                              long long rows, int bins, long long F,
+                                                              const int* __restrict__ idx, int n_sel,
+                                                              float n_std, float* __restrict__ thr) {
+  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= rows * bins) return;
+  const long long row = g / bins;
+  const float* __restrict__ line = mag + g * F;
+  const int* __restrict__ sel = idx ? idx + row * n_sel : nullptr;
+  const int n = sel ? n_sel : (int)F;
+  float sum = 0.0f;
+  for (int q = 0; q < n; ++q) sum += line[sel ? sel[q] : q];
+  const float mean = sum / (float)n;
+  float ss = 0.0f;
+  for (int q = 0; q < n; ++q) {
+    const float d = line[sel ? sel[q] : q] - mean;
+    ss += d * d;
+  }
+  thr[g] = mean + n_std * sqrtf(ss / (float)n);
+}
+
+// out[r, i] = min of x[r, clamp(j)] over j in [i - size/2, i + (size-1)/2]
+__global__ __launch_bounds__(256) void time_min_filter_kernel(const float* __restrict__ x,
+                                                              long long rows, long long n, int size,
+                                                              float* __restrict__ out) {
+  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= rows * n) return;
+  const long long r = g / n, i = g - r * n;
+  const float* __restrict__ line = x + r * n;
+  float m = INFINITY;
+  for (long long j = i - size / 2; j <= i + (size - 1) / 2; ++j) {
+    const long long q = j < 0 ? 0 : (j >= n ? n - 1 : j);
+    m = fminf(m, line[q]);
+  }
+  out[g] = m;
+}
+
+// Moving average along the middle axis of x viewed as (outer, n, inner), window
+// [i - size/2, i + (size-1)/2] with indices clamped to the ends; the sum runs in double.
+__global__ __launch_bounds__(256) void box_filter_kernel(const float* __restrict__ x,
+                                                         long long outer, long long n,
+                                                         long long inner, int size,
+                                                         float* __restrict__ out) {
+  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= outer * n * inner) return;
+  const long long in = g % inner;
+  const long long i = (g / inner) % n;
+  const long long o = g / (inner * n);
+  const float* __restrict__ line = x + o * n * inner + in;
+  double sum = 0.0;
+  for (long long j = i - size / 2; j <= i + (size - 1) / 2; ++j) {
+    const long long q = j < 0 ? 0 : (j >= n ? n - 1 : j);
+    sum += (double)line[q * inner];
+  }
+  out[g] = (float)(sum / (double)size);
+}
+
+// mask = clip((mag - thr * gain) / (mag + eps), 0, 1); thr is (rows, bins, frames) or, with
+// per_bin, (rows_thr, bins) broadcast over frames (rows_thr = rows, or 1 shared by all rows)
+__global__ __launch_bounds__(256) void gate_mask_kernel(const float* __restrict__ mag,
+                                                        const float* __restrict__ thr, long long rows,
+                                                        int bins, long long F, int per_bin,
+                                                        long long rows_thr, float gain,
+                                                        float* __restrict__ mask) {
+  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= rows * bins * F) return;
+  float t;
+  if (per_bin) {
+    const long long rb = g / F;  // row * bins + bin
+    t = thr[rows_thr == 1 ? rb % bins : rb];
+  } else {
+    t = thr[g];
+  }
+  const float m = mag[g];
+  const float v = (m - t * gain) / (m + kGateEps);
+  mask[g] = fminf(fmaxf(v, 0.0f), 1.0f);
+}
+
+// op 0: out = 1 - p (1 - a);  op 1: out = a * b
+__global__ __launch_bounds__(256) void mask_op_kernel(const float* __restrict__ a,
+                                                      const float* __restrict__ b, long long n,
+                                                      int op, float p, float* __restrict__ out) {
+  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n) return;
+  out[g] = op == 0 ? 1.0f - p * (1.0f - a[g]) : a[g] * b[g];
+}
+
+static inline unsigned gate_blocks(long long n) { return (unsigned)((n + 255) / 256); }
+
+}  // namespace mia
+
+extern "C" {
+
+int mia_frame_energy(const float* mag, int64_t rows, int bins, int64_t frames, float* energy,
+                     void* stream) {
+  using namespace mia;
+  MIA_REQUIRE(rows >= 0 && bins >= 1 && frames >= 0, "rows, bins, frames must be >= 0, 1, 0");
+  if (rows == 0 || frames == 0) return MIA_OK;
+  MIA_REQUIRE(mag && energy, "null pointer");
+  hipLaunchKernelGGL(frame_energy_kernel, dim3(gate_blocks(rows * frames)), dim3(256), 0,
+                     (hipStream_t)stream, mag, (long long)rows, bins, (long long)frames, energy);
+  MIA_CHECK_HIP(hipGetLastError());
+  return MIA_OK;
+}
+
+int mia_noise_threshold(const float* mag, int64_t rows, int bins, int64_t frames, const int* frame_idx,
+                        int n_selected, float n_std, float* thr, void* stream) {
+  using namespace mia;
+  MIA_REQUIRE(rows >= 0 && bins >= 1 && frames >= 1, "rows, bins, frames must be >= 0, 1, 1");
+  MIA_REQUIRE(frame_idx == nullptr || n_selected >= 1, "n_selected must be >= 1");
+  MIA_REQUIRE(frames <= 0x7fffffffLL, "too many frames");
+  if (rows == 0) return MIA_OK;
+  MIA_REQUIRE(mag && thr, "null pointer");
+  hipLaunchKernelGGL(noise_threshold_kernel, dim3(gate_blocks(rows * bins)), dim3(256), 0,
+                     (hipStream_t)stream, mag, (long long)rows, bins, (long long)frames, frame_idx,
+                     n_selected, n_std, thr);
+  MIA_CHECK_HIP(hipGetLastError());
+  return MIA_OK;
+}
+
+int mia_time_min_filter(const float* x, int64_t rows, int64_t n, int size, float* out, void* stream) {
+  using namespace mia;
+  MIA_REQUIRE(rows >= 0 && n >= 0 && size >= 1, "rows, n, size must be >= 0, 0, 1");
+  if (rows == 0 || n == 0) return MIA_OK;
+  MIA_REQUIRE(x && out && x != out, "null or aliased pointers");
+  hipLaunchKernelGGL(time_min_filter_kernel, dim3(gate_blocks(rows * n)), dim3(256), 0,
+                     (hipStream_t)stream, x, (long long)rows, (long long)n, size, out);
+  MIA_CHECK_HIP(hipGetLastError());
+  return MIA_OK;
+}
+
+int mia_box_filter(const float* x, int64_t outer, int64_t n, int64_t inner, int size, float* out,
+                   void* stream) {
+  using namespace mia;
+  MIA_REQUIRE(outer >= 0 && n >= 0 && inner >= 0 && size >= 1,
+              "outer, n, inner, size must be >= 0, 0, 0, 1");
+  if (outer == 0 || n == 0 || inner == 0) return MIA_OK;
+  MIA_REQUIRE(x && out && x != out, "null or aliased pointers");
+  hipLaunchKernelGGL(box_filter_kernel, dim3(gate_blocks(outer * n * inner)), dim3(256), 0,
+                     (hipStream_t)stream, x, (long long)outer, (long long)n, (long long)inner, size,
+                     out);
+  MIA_CHECK_HIP(hipGetLastError());
+  return MIA_OK;
+}
+
+int mia_gate_mask(const float* mag, const float* thr, int64_t rows, int bins, int64_t frames,
+                  int per_bin, int64_t rows_thr, float gain, float* mask, void* stream) {
+  using namespace mia;
+  MIA_REQUIRE(rows >= 0 && bins >= 1 && frames >= 0, "rows, bins, frames must be >= 0, 1, 0");
+  MIA_REQUIRE(rows_thr == rows || (per_bin && rows_thr == 1),
+              "the threshold must have one row per signal row, or a single row of per-bin values");
+  if (rows == 0 || frames == 0) return MIA_OK;
+  MIA_REQUIRE(mag && thr && mask, "null pointer");
+  hipLaunchKernelGGL(gate_mask_kernel, dim3(gate_blocks(rows * bins * frames)), dim3(256), 0,
+                     (hipStream_t)stream, mag, thr, (long long)rows, bins, (long long)frames,
+                     per_bin, (long long)rows_thr, gain, mask);
+  MIA_CHECK_HIP(hipGetLastError());
+  return MIA_OK;
+}
+
+int mia_mask_op(const float* a, const float* b, int64_t n, int op, float p, float* out, void* stream) {
+  using namespace mia;
+  MIA_REQUIRE(n >= 0 && (op == 0 || op == 1), "n must be >= 0 and op 0 or 1");
+  if (n == 0) return MIA_OK;
+  MIA_REQUIRE(a && out && (op == 0 || b), "null pointer");
+  hipLaunchKernelGGL(mask_op_kernel, dim3(gate_blocks(n)), dim3(256), 0, (hipStream_t)stream, a, b,
+                     (long long)n, op, p, out);
+  MIA_CHECK_HIP(hipGetLastError());
+  return MIA_OK;
+}
+
+}  // extern "C"

@@ -10,6 +10,7 @@ from .mel import hz_to_mel, mel_filterbank, mel_to_hz, melspectrogram
 from .mfcc import dct, mfcc
 from .onset import onset_detect, onset_strength, onset_strength_multi
 from .resample import resample, resample_poly
+from .spectral_gate import spectral_gate, spectral_gate_adaptive
 from .stft import check_nola, istft, magnitude, phase, stft
 from .windows import get_window
 
@@ -24,4 +25,5 @@ __all__ = [
     "spectral_contrast", "zero_crossing_rate",
     "onset_strength", "onset_detect", "onset_strength_multi",
     "griffinlim", "griffinlim_iter",
+    "spectral_gate", "spectral_gate_adaptive",
 ]

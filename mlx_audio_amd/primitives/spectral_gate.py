@@ -1,0 +1,179 @@
+"""Spectral gating noise reduction on MI355X with the signatures of
+`mlx_audio.primitives.spectral_gate` (reference python/mlx_audio/primitives/spectral_gate.py).
+
+The reference computes the STFT on its array library, moves magnitude and phase to the host,
+builds the gate mask in NumPy / scipy.ndimage and goes back for the inverse STFT.  Here every
+step stays on the GPU; the only host work is choosing the quietest tenth of the frames (a sort
+of one number per frame, done with NumPy as in the reference).
+"""
+
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from .. import _lib
+from .._runtime import as_device_f32, stream_ptr
+from .griffinlim import _polar
+from .stft import istft, magnitude, phase, stft
+
+
+def _validate(n_fft, hop_length, prop_decrease) -> None:
+    if n_fft <= 0:
+        raise ValueError(f"n_fft must be positive, got {n_fft}")
+    if hop_length <= 0:
+        raise ValueError(f"hop_length must be positive, got {hop_length}")
+    if prop_decrease < 0.0:
+        raise ValueError(f"prop_decrease must be >= 0.0, got {prop_decrease}")
+    if prop_decrease > 1.0:
+        raise ValueError(f"prop_decrease must be <= 1.0, got {prop_decrease}")
+
+
+class _Ops:
+    """Thin launcher around the gating entry points for one device."""
+
+    def __init__(self, device):
+        self.dev = device
+        self.lib = _lib.lib()
+
+    def _run(self, name, *args):
+        with torch.cuda.device(self.dev):
+            _lib.check(getattr(self.lib, name)(*args, stream_ptr(self.dev)))
+
+    def new(self, shape):
+        return torch.empty(shape, dtype=torch.float32, device=self.dev)
+
+    def frame_energy(self, mag):
+        rows, bins, frames = mag.shape
+        out = self.new((rows, frames))
+        self._run("mia_frame_energy", mag.data_ptr(), rows, bins, frames, out.data_ptr())
+        return out
+
+    def noise_threshold(self, mag, idx, n_std):
+        rows, bins, frames = mag.shape
+        out = self.new((rows, bins))
+        self._run("mia_noise_threshold", mag.data_ptr(), rows, bins, frames,
+                  0 if idx is None else idx.data_ptr(), 0 if idx is None else idx.shape[1],
+                  float(n_std), out.data_ptr())
+        return out
+
+    def time_min(self, x, size):
+        rows, bins, frames = x.shape
+        out = self.new(x.shape)
+        self._run("mia_time_min_filter", x.data_ptr(), rows * bins, frames, int(size), out.data_ptr())
+        return out
+
+    def box(self, x, size_freq, size_time):
+        """scipy.ndimage.uniform_filter(x, size=(1, size_freq, size_time), mode='nearest'):
+        one moving average per axis whose size exceeds 1, frequency axis first."""
+        rows, bins, frames = x.shape
+        if size_freq > 1:
+            out = self.new(x.shape)
+            self._run("mia_box_filter", x.data_ptr(), rows, bins, frames, int(size_freq), out.data_ptr())
+            x = out
+        if size_time > 1:
+            out = self.new(x.shape)
+            self._run("mia_box_filter", x.data_ptr(), rows * bins, frames, 1, int(size_time), out.data_ptr())
+            x = out
+        return x
+
+    def mask(self, mag, thr, gain):
+        rows, bins, frames = mag.shape
+        out = self.new(mag.shape)
+        per_bin = thr.dim() == 2
+        self._run("mia_gate_mask", mag.data_ptr(), thr.data_ptr(), rows, bins, frames, int(per_bin),
+                  thr.shape[0], float(gain), out.data_ptr())
+        return out
+
+    def keep(self, mask, prop_decrease):
+        out = self.new(mask.shape)
+        self._run("mia_mask_op", mask.data_ptr(), 0, mask.numel(), 0, float(prop_decrease), out.data_ptr())
+        return out
+
+    def times(self, a, b):
+        out = self.new(a.shape)
+        self._run("mia_mask_op", a.data_ptr(), b.data_ptr(), a.numel(), 1, 0.0, out.data_ptr())
+        return out
+
+
+def spectral_gate(audio, noise_profile=None, *, sr: int = 22050, n_fft: int = 2048,
+                  hop_length=None, win_length=None, window: str = "hann",
+                  threshold_db: float = -20.0, prop_decrease: float = 1.0,
+                  n_std_thresh: float = 1.5, time_constant_s: float = 0.05,
+                  freq_smooth_hz: float = 100.0, time_smooth_ms: float = 10.0,
+                  stationary: bool = True, n_grad_freq: int = 2,
+                  n_grad_time: int = 4) -> torch.Tensor:
+    """Spectral gating noise reduction (reference spectral_gate.py:19-238)."""
+    if hop_length is None:
+        hop_length = n_fft // 4
+    if win_length is None:
+        win_length = n_fft
+    _validate(n_fft, hop_length, prop_decrease)
+    x = as_device_f32(audio)
+    is_1d = x.dim() == 1
+    if is_1d:
+        x = x[None]
+    n_samples = x.shape[-1]
+    kw = dict(n_fft=n_fft, hop_length=hop_length, win_length=win_length, window=window, center=True)
+    C = stft(x, **kw).contiguous()   # (rows, bins, frames) in memory: one transposing copy, not two
+    mag, ph = magnitude(C), phase(C)
+    ops = _Ops(mag.device)
+    rows, bins, frames = mag.shape
+
+    if noise_profile is not None:
+        noise = as_device_f32(noise_profile)
+        noise_mag = magnitude(stft(noise if noise.dim() > 1 else noise[None], **kw))
+        if noise_mag.shape[0] not in (1, rows):
+            raise ValueError(f"noise_profile has {noise_mag.shape[0]} rows, the audio {rows}")
+        thr = ops.noise_threshold(noise_mag, None, n_std_thresh)
+    elif stationary:
+        energy = ops.frame_energy(mag).cpu().numpy()
+        n_quiet = max(1, int(0.1 * frames))
+        quiet = np.stack([np.argsort(energy[b])[:n_quiet] for b in range(rows)]).astype(np.int32)
+        thr = ops.noise_threshold(mag, torch.from_numpy(quiet).to(mag.device), n_std_thresh)
+    else:
+        tc_frames = max(1, int(time_constant_s * sr / hop_length))
+        thr = ops.time_min(mag, tc_frames)
+
+    gain = 10 ** (threshold_db / 20.0)
+    if noise_profile is None and not stationary:
+        gain *= (1 + n_std_thresh)
+    mask = ops.mask(mag, thr, gain)
+    if freq_smooth_hz > 0 or time_smooth_ms > 0:
+        fb = max(1, int(freq_smooth_hz * n_fft / sr))
+        tf = max(1, int(time_smooth_ms * sr / (1000 * hop_length)))
+        mask = ops.box(mask, fb, tf)
+    if n_grad_freq > 1 or n_grad_time > 1:
+        mask = ops.box(mask, n_grad_freq, n_grad_time)
+    mask = ops.keep(mask, prop_decrease)
+    enhanced = _polar(ops.times(mag, mask), ph)
+    y = istft(enhanced, hop_length=hop_length, win_length=win_length, window=window, center=True,
+              length=n_samples)
+    return y[0] if is_1d else y
+
+
+def spectral_gate_adaptive(audio, *, sr: int = 22050, n_fft: int = 2048, hop_length=None,
+                           threshold_db: float = -20.0, prop_decrease: float = 1.0,
+                           look_ahead_ms: float = 100.0,
+                           look_back_ms: float = 100.0) -> torch.Tensor:
+    """Spectral gating with a running-minimum noise floor (reference spectral_gate.py:241-353)."""
+    if hop_length is None:
+        hop_length = n_fft // 4
+    _validate(n_fft, hop_length, prop_decrease)
+    ahead = max(1, int(look_ahead_ms * sr / (1000 * hop_length)))
+    back = max(1, int(look_back_ms * sr / (1000 * hop_length)))
+    x = as_device_f32(audio)
+    is_1d = x.dim() == 1
+    if is_1d:
+        x = x[None]
+    n_samples = x.shape[-1]
+    C = stft(x, n_fft=n_fft, hop_length=hop_length, center=True).contiguous()
+    mag, ph = magnitude(C), phase(C)
+    ops = _Ops(mag.device)
+    floor = ops.time_min(mag, ahead + back + 1)
+    mask = ops.mask(mag, floor, 1.0 + 10 ** (threshold_db / 20.0))
+    mask = ops.keep(mask, prop_decrease)
+    mask = ops.box(mask, 3, 5)
+    enhanced = _polar(ops.times(mag, mask), ph)
+    y = istft(enhanced, hop_length=hop_length, center=True, length=n_samples)
+    return y[0] if is_1d else y

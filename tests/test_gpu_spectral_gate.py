@@ -1,0 +1,140 @@
+"""Spectral gating on the GPU against the oracle (NumPy + scipy.ndimage, the reference's own
+host arithmetic for the mask), through the C ABI.  The mask steps are compared one by one on
+identical inputs (1e-6: float32 sums in another order), the whole functions on waveforms
+(2e-4 of the peak: the STFT pair's rounding enters the choice of the quietest frames only through
+values, the frame sets are compared explicitly)."""
+
+import numpy as np
+import pytest
+import torch
+from scipy.ndimage import minimum_filter1d, uniform_filter
+
+import oracle.spectral_gate as orc
+from mlx_audio_amd import _lib
+from mlx_audio_amd.primitives import spectral_gate, spectral_gate_adaptive
+from mlx_audio_amd.primitives.spectral_gate import _Ops
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(a, gpu):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(gpu)
+
+
+def _noisy(rows=2, n=22050, seed=0):
+    rng = np.random.default_rng(seed)
+    t = np.arange(n) / 22050.0
+    y = np.stack([np.sin(2 * np.pi * (330 + 110 * r) * t) * (t > 0.25 + 0.1 * r) for r in range(rows)])
+    return (y + 0.05 * rng.standard_normal((rows, n))).astype(np.float32)
+
+
+def test_mask_building_blocks(gpu):
+    rng = np.random.default_rng(1)
+    mag = np.abs(rng.standard_normal((3, 65, 120))).astype(np.float32)
+    ops = _Ops(gpu)
+    d = _dev(mag, gpu)
+    np.testing.assert_allclose(ops.frame_energy(d).cpu().numpy(), np.mean(mag ** 2, axis=1), rtol=2e-6)
+    want = np.mean(mag, axis=-1) + 1.5 * np.std(mag, axis=-1)
+    np.testing.assert_allclose(ops.noise_threshold(d, None, 1.5).cpu().numpy(), want, rtol=3e-6)
+    idx = np.stack([rng.permutation(120)[:12] for _ in range(3)]).astype(np.int32)
+    sel = np.stack([mag[b][:, idx[b]] for b in range(3)])
+    want = np.mean(sel, axis=-1) + 2.0 * np.std(sel, axis=-1)
+    np.testing.assert_allclose(ops.noise_threshold(d, _dev(idx, gpu), 2.0).cpu().numpy(), want, rtol=3e-6)
+    for size in (1, 2, 5, 18, 300):
+        np.testing.assert_array_equal(ops.time_min(d, size).cpu().numpy(),
+                                      minimum_filter1d(mag, size=size, axis=-1, mode="nearest"))
+    for fb, tf in ((9, 1), (2, 4), (3, 5), (1, 1), (70, 130)):
+        np.testing.assert_allclose(ops.box(d, fb, tf).cpu().numpy(),
+                                   uniform_filter(mag, size=(1, fb, tf), mode="nearest"), rtol=0, atol=1e-6)
+    thr = np.abs(rng.standard_normal((3, 65))).astype(np.float32)
+    want = np.clip((mag - thr[:, :, None] * 0.1) / (mag + 1e-8), 0.0, 1.0)
+    np.testing.assert_allclose(ops.mask(d, _dev(thr, gpu), 0.1).cpu().numpy(), want, rtol=0, atol=1e-6)
+    want1 = np.clip((mag - thr[:1, :, None] * 0.1) / (mag + 1e-8), 0.0, 1.0)
+    np.testing.assert_allclose(ops.mask(d, _dev(thr[:1], gpu), 0.1).cpu().numpy(), want1, rtol=0, atol=1e-6)
+    full = np.abs(rng.standard_normal(mag.shape)).astype(np.float32)
+    want = np.clip((mag - full * 0.5) / (mag + 1e-8), 0.0, 1.0)
+    np.testing.assert_allclose(ops.mask(d, _dev(full, gpu), 0.5).cpu().numpy(), want, rtol=0, atol=1e-6)
+    m = ops.mask(d, _dev(full, gpu), 0.5)
+    np.testing.assert_allclose(ops.keep(m, 0.8).cpu().numpy(), 1.0 - 0.8 * (1.0 - want), rtol=0, atol=1e-6)
+    np.testing.assert_array_equal(ops.times(d, m).cpu().numpy(), mag * m.cpu().numpy())
+
+
+def test_whole_mask_matches_the_oracle(gpu):
+    """gate_mask of the oracle against the same sequence of launches on identical magnitudes."""
+    rng = np.random.default_rng(2)
+    mag = np.abs(rng.standard_normal((2, 1025, 44))).astype(np.float32)
+    ops = _Ops(gpu)
+    d = _dev(mag, gpu)
+    # non-stationary branch
+    want = orc.gate_mask(mag, stationary=False)
+    tc = max(1, int(0.05 * 22050 / 512))
+    m = ops.mask(d, ops.time_min(d, tc), 10 ** (-20 / 20.0) * 2.5)
+    m = ops.keep(ops.box(ops.box(m, 9, 1), 2, 4), 1.0)
+    np.testing.assert_allclose(m.cpu().numpy(), want, rtol=0, atol=2e-6)
+    want = orc.adaptive_mask(mag)
+    a = max(1, int(100.0 * 22050 / (1000 * 512)))
+    m = ops.box(ops.keep(ops.mask(d, ops.time_min(d, 2 * a + 1), 1.1), 1.0), 3, 5)
+    np.testing.assert_allclose(m.cpu().numpy(), want, rtol=0, atol=2e-6)
+
+
+@pytest.mark.parametrize("kw", [{}, {"stationary": False}, {"prop_decrease": 0.6, "threshold_db": -10.0},
+                                {"n_fft": 1024, "hop_length": 256, "freq_smooth_hz": 0.0, "time_smooth_ms": 0.0},
+                                {"n_grad_freq": 1, "n_grad_time": 1, "time_smooth_ms": 60.0},
+                                {"window": "hamming", "win_length": 1500}])
+def test_spectral_gate_matches_the_oracle(gpu, kw):
+    y = _noisy()
+    got = spectral_gate(_dev(y, gpu), **kw).cpu().numpy()
+    want = orc.spectral_gate(y, **kw)
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() <= 2e-4 * np.abs(want).max()
+    one = spectral_gate(_dev(y[0], gpu), **kw).cpu().numpy()
+    assert np.abs(one - orc.spectral_gate(y[0], **kw)).max() <= 2e-4 * np.abs(want).max()
+
+
+def test_noise_profile_and_adaptive(gpu):
+    y = _noisy()
+    for prof in (y[0, :4000], y[:, :4000]):
+        got = spectral_gate(_dev(y, gpu), noise_profile=_dev(prof, gpu)).cpu().numpy()
+        want = orc.spectral_gate(y, noise_profile=prof)
+        assert np.abs(got - want).max() <= 2e-4 * np.abs(want).max()
+    for kw in ({}, {"threshold_db": -6.0, "prop_decrease": 0.7, "look_ahead_ms": 30.0}, {"n_fft": 512}):
+        got = spectral_gate_adaptive(_dev(y, gpu), **kw).cpu().numpy()
+        want = orc.spectral_gate_adaptive(y, **kw)
+        assert np.abs(got - want).max() <= 2e-4 * np.abs(want).max()
+    with pytest.raises(ValueError, match="noise_profile has 3 rows"):
+        spectral_gate(_dev(y, gpu), noise_profile=_dev(np.zeros((3, 4000), np.float32), gpu))
+
+
+def test_behaviour_and_c_abi_checks(gpu):
+    y = _noisy(rows=1)[0]
+    out = spectral_gate(_dev(y, gpu)).cpu().numpy()
+    assert np.abs(out[:4000]).mean() < 0.9 * np.abs(y[:4000]).mean()
+    np.testing.assert_allclose(spectral_gate(_dev(y, gpu), prop_decrease=0.0).cpu().numpy(), y, atol=1e-5)
+    lib = _lib.lib()
+    a = torch.ones((2, 4, 6), device=gpu)
+    o = torch.zeros((2, 4, 6), device=gpu)
+    s = torch.cuda.current_stream(gpu).cuda_stream
+    assert lib.mia_time_min_filter(a.data_ptr(), 8, 6, 0, o.data_ptr(), s) == _lib.MIA_ERR_INVALID
+    assert lib.mia_time_min_filter(a.data_ptr(), 8, 6, 3, a.data_ptr(), s) == _lib.MIA_ERR_INVALID
+    assert lib.mia_box_filter(a.data_ptr(), 2, 4, 6, 0, o.data_ptr(), s) == _lib.MIA_ERR_INVALID
+    assert lib.mia_gate_mask(a.data_ptr(), a.data_ptr(), 2, 4, 6, 0, 1, 1.0, o.data_ptr(), s) == _lib.MIA_ERR_INVALID
+    assert lib.mia_mask_op(a.data_ptr(), 0, 48, 1, 0.0, o.data_ptr(), s) == _lib.MIA_ERR_INVALID
+    assert lib.mia_mask_op(a.data_ptr(), 0, 48, 2, 0.0, o.data_ptr(), s) == _lib.MIA_ERR_INVALID
+    assert lib.mia_noise_threshold(a.data_ptr(), 2, 4, 0, 0, 0, 1.0, o.data_ptr(), s) == _lib.MIA_ERR_INVALID
+    assert lib.mia_frame_energy(a.data_ptr(), 0, 4, 6, o.data_ptr(), s) == _lib.MIA_OK
+
+
+def test_full_size_batch(gpu):
+    """64 x 10 s @22.05 kHz: spot rows against the oracle, batch invariance bit for bit."""
+    g = torch.Generator(device=gpu)
+    g.manual_seed(2)
+    y = 0.05 * torch.randn((64, 220500), generator=g, device=gpu)
+    t = torch.arange(220500, device=gpu) / 22050.0
+    y = y + torch.sin(2 * np.pi * 440 * t) * (t > 2.0)
+    out = spectral_gate(y)
+    assert out.shape == y.shape
+    rows = [0, 63]
+    want = orc.spectral_gate(y[rows].cpu().numpy())
+    assert np.abs(out[rows].cpu().numpy() - want).max() <= 2e-4 * np.abs(want).max()
+    assert torch.equal(spectral_gate(y[5:9]), out[5:9])
+    assert out[:, :22050].abs().mean() < 0.9 * y[:, :22050].abs().mean()
