@@ -19,6 +19,7 @@ Workloads (config.workload):
   onset       onset strength of 4096 mel spectrograms (128 x 938)
   griffinlim  8 Griffin-Lim iterations on 64 x 10 s @22.05 kHz, n_fft 2048 / hop 512
   spectral_gate  spectral gating of 64 x 10 s @22.05 kHz
+  demucs_front   HTDemucs spectrogram + input normalisation, 16 stereo x 60 s @44.1 kHz
 """
 
 from __future__ import annotations
@@ -157,6 +158,17 @@ def make_workload(name: str, clips: int, device, seed: int):
         return (lambda: spectral_gate(y), clips * 10.0 / 3600.0, abytes,
                 f"spectral gating (stationary noise estimate, default smoothing), {clips} x 10 s "
                 "@22.05 kHz, n_fft 2048 hop 512", "spectral gate audio-hours/sec")
+    if name == "demucs_front":
+        from mlx_audio_amd.frontends import htdemucs_normalize
+
+        T = 44100 * 60
+        mix = 0.1 * torch.randn((clips, 2, T), generator=gen, device=device, dtype=torch.float32)
+        frames = -(-T // 1024)
+        abytes = clips * 2 * (T * 4 + 2048 * frames * 8 + T * 4)
+        return (lambda: htdemucs_normalize(mix), clips * 60.0 / 3600.0, abytes,
+                f"HTDemucs model input: spectrogram (n_fft 4096, hop 1024) + complex-as-channels "
+                f"normalisation + waveform normalisation, {clips} stereo x 60 s @44.1 kHz",
+                "HTDemucs front-end track-hours/sec")
     raise SystemExit(f"unknown workload {name}")
 
 
@@ -167,6 +179,7 @@ KERNEL_OF = {
     "htdemucs": "fwd_kernel<4096> then istft_kernel<4096> (fused inverse FFT + overlap-add)",
     "resample": "upfirdn_kernel (polyphase FIR, input span and phase table staged in LDS)",
     "contrast": "spectral_contrast_kernel<16> (one thread per frame, sorted register arrays)",
+    "demucs_front": "fwd_kernel<4096> + cac_moments_kernel + cac_normalize_kernel + row kernels",
     "spectral_gate": "fwd_kernel<2048> + magnitude/phase + 9 mask kernels + polar + istft_kernel<2048>",
     "griffinlim": "per iteration istft_kernel<2048> + fwd_kernel<2048> + griffinlim_update_kernel",
     "onset": "onset_flux_shift_kernel (a wave per 64 frames, lagged values by lane shift)",
@@ -268,7 +281,7 @@ def main() -> None:
               "torch.distributed.run for N>1", file=sys.stderr)
 
     default_clips = {"whisper128": 1024, "clap64": 1024, "mfcc40": 1024, "htdemucs": 32,
-                     "resample": 512, "resample_fft": 64, "features": 512, "contrast": 512, "onset": 4096, "griffinlim": 64, "spectral_gate": 64}
+                     "resample": 512, "resample_fft": 64, "features": 512, "contrast": 512, "onset": 4096, "griffinlim": 64, "spectral_gate": 64, "demucs_front": 16}
     clips = args.clips or default_clips.get(args.workload, 1024)
     step, units, abytes, desc, metric = make_workload(args.workload, clips, device, 1234 + rank)
 
@@ -323,7 +336,7 @@ def main() -> None:
         line = {
             "metric": metric,
             "value": value,
-            "unit": "audio-hours/s" if args.workload != "htdemucs" else "track-hours/s",
+            "unit": "track-hours/s" if args.workload in ("htdemucs", "demucs_front") else "audio-hours/s",
             "n_gpus": n_gpus,
             "steps": args.steps,
             "warmup": args.warmup,

@@ -314,6 +314,22 @@ int mia_gate_mask(const float* mag, const float* thr, int64_t rows, int bins, in
                   int per_bin, int64_t rows_thr, float gain, float* mask, void* stream);
 int mia_mask_op(const float* a, const float* b, int64_t n, int op, float p, float* out, void* stream);
 
+/* ---- HTDemucs input normalisation (models/demucs/model.py:206-233) ---------------------
+ * mia_normalize_rows: per row of n floats, mean and population standard deviation, then
+ *   out = (x - mean) / (std + eps) (the time branch, model.py:231-233, a batch item's channels
+ *   and samples being one row); stats: device (rows, 2) = {mean, std + eps}, what the model
+ *   later multiplies and adds back (model.py:367); sums: device scratch of rows * 16 bytes.
+ * mia_normalize_cac: the frequency branch (model.py:209-227): spec is a complex64 array
+ *   [batch, channels, bins, frames] addressed through strides in complex elements (e.g. the
+ *   strided view of mia_stft's (rows, frames, bins) output); its real and imaginary parts
+ *   become planes 2c and 2c+1 of out: device float (batch, 2*channels, bins, frames),
+ *   normalised by the mean and std over all of a batch item's planes. */
+int mia_normalize_rows(const float* x, int64_t rows, int64_t n, float eps, float* out, float* stats,
+                       void* sums, void* stream);
+int mia_normalize_cac(const void* spec, int64_t batch, int channels, int64_t bins, int64_t frames,
+                      int64_t stride_b, int64_t stride_c, int64_t stride_f, int64_t stride_t,
+                      float eps, float* out, float* stats, void* sums, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

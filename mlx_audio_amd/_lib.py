@@ -100,6 +100,10 @@ SIGNATURES = {
     "mia_gate_mask": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int64, c_int, c_int64, c_float,
                               c_void_p, c_void_p]),
     "mia_mask_op": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p, c_void_p]),
+    "mia_normalize_rows": (c_int, [c_void_p, c_int64, c_int64, c_float, c_void_p, c_void_p, c_void_p,
+                                   c_void_p]),
+    "mia_normalize_cac": (c_int, [c_void_p, c_int64, c_int, c_int64, c_int64, c_int64, c_int64,
+                                  c_int64, c_int64, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mia_polar": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "mia_griffinlim_update": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float,
                                       c_void_p]),

@@ -1,0 +1,184 @@
+// Input normalisation of the HTDemucs front-end: per batch item, mean and standard deviation
+// over everything that item holds (all channels, bins and frames of the spectrogram taken as
+// real and imaginary planes; all channels and samples of the waveform), then (x - mean) /
+// (std + eps).  Sums run in double (per-thread partials, a workgroup reduction, one atomic
+// pair per workgroup); the spectrogram is read through its strides, as the strided view of the
+// STFT kernel's (rows, frames, bins) output that the front-end hands over, and written as
+// (batch, 2*channels, bins, frames) planes through an LDS tile so that both sides are coalesced.
+#include "mia_internal.h"
+
+namespace mia {
+
+__device__ __forceinline__ void block_accumulate(double s, double q, double* __restrict__ dst) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    s += __shfl_xor(s, off);
+    q += __shfl_xor(q, off);
+  }
+  __shared__ double red[2][4];
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    red[0][wave] = s;
+    red[1][wave] = q;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(dst, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+    atomicAdd(dst + 1, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+  }
+}
+
+// sums[row] += {sum x, sum x^2} over a contiguous row of n floats; grid (chunks, rows)
+__global__ __launch_bounds__(256) void row_moments_kernel(const float* __restrict__ x, long long n,
+                                                          double* __restrict__ sums) {
+  const long long row = blockIdx.y;
+  const float* __restrict__ line = x + row * n;
+  double s = 0.0, q = 0.0;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const double v = (double)line[i];
+    s += v;
+    q += v * v;
+  }
+  block_accumulate(s, q, sums + 2 * row);
+}
+
+// the same over the complex elements spec[b, c, f, t] (strides in complex elements), both
+// parts; grid (chunks, batch * channels): a workgroup takes frames chunk, chunk + chunks, ... of
+// one plane, its threads stride the bins (no index division in the loop)
+__global__ __launch_bounds__(256) void cac_moments_kernel(const float2* __restrict__ spec, int C,
+                                                          long long F, long long T, long long sb,
+                                                          long long sc, long long sf, long long st,
+                                                          double* __restrict__ sums) {
+  const long long bc = blockIdx.y, b = bc / C, c = bc - b * C;
+  const float2* __restrict__ plane = spec + b * sb + c * sc;
+  double s = 0.0, q = 0.0;
+  for (long long t = blockIdx.x; t < T; t += gridDim.x) {
+    const float2* __restrict__ line = plane + t * st;
+    for (long long f = threadIdx.x; f < F; f += 256) {
+      const float2 z = line[f * sf];
+      s += (double)z.x + (double)z.y;
+      q += (double)z.x * (double)z.x + (double)z.y * (double)z.y;
+    }
+  }
+  block_accumulate(s, q, sums + 2 * b);
+}
+
+__device__ __forceinline__ void mean_std(const double* __restrict__ sums, double count, float eps,
+                                         float& mean, float& inv) {
+  const double m = sums[0] / count;
+  double var = sums[1] / count - m * m;
+  if (var < 0.0) var = 0.0;
+  mean = (float)m;
+  inv = 1.0f / ((float)sqrt(var) + eps);
+}
+
+__global__ __launch_bounds__(256) void row_normalize_kernel(const float* __restrict__ x, long long n,
+                                                            const double* __restrict__ sums,
+                                                            float eps, float* __restrict__ out,
+                                                            float* __restrict__ stats) {
+  const long long row = blockIdx.y;
+  float mean, inv;
+  mean_std(sums + 2 * row, (double)n, eps, mean, inv);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    stats[2 * row] = mean;
+    stats[2 * row + 1] = 1.0f / inv;
+  }
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    out[row * n + i] = (x[row * n + i] - mean) * inv;
+  }
+}
+
+// out[b, 2c + part, f, t] = (part of spec[b, c, f, t] - mean_b) / (std_b + eps); 32 x 32 tiles
+// of (f, t) go through LDS: read with f fastest, written with t fastest.  grid (tiles_t,
+// tiles_f, B*C), block (32, 8).
+__global__ __launch_bounds__(256) void cac_normalize_kernel(const float2* __restrict__ spec, int C,
+                                                            long long F, long long T, long long sb,
+                                                            long long sc, long long sf, long long st,
+                                                            const double* __restrict__ sums,
+                                                            float eps, float* __restrict__ out,
+                                                            float* __restrict__ stats) {
+  __shared__ float2 tile[32][33];
+  const long long bc = blockIdx.z, b = bc / C, c = bc - b * C;
+  float mean, inv;
+  mean_std(sums + 2 * b, 2.0 * (double)C * (double)F * (double)T, eps, mean, inv);
+  if (c == 0 && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && threadIdx.y == 0) {
+    stats[2 * b] = mean;
+    stats[2 * b + 1] = 1.0f / inv;
+  }
+  const long long f0 = (long long)blockIdx.y * 32, t0 = (long long)blockIdx.x * 32;
+  const float2* __restrict__ src = spec + b * sb + c * sc;
+  for (int j = threadIdx.y; j < 32; j += 8) {  // j: frame within the tile, x: bin
+    const long long f = f0 + threadIdx.x, t = t0 + j;
+    float2 z = {0.0f, 0.0f};
+    if (f < F && t < T) z = src[f * sf + t * st];
+    tile[j][threadIdx.x] = z;
+  }
+  __syncthreads();
+  float* __restrict__ re = out + ((b * 2 * C + 2 * c) * F) * T;
+  float* __restrict__ im = re + F * T;
+  for (int j = threadIdx.y; j < 32; j += 8) {  // j: bin within the tile, x: frame
+    const long long f = f0 + j, t = t0 + threadIdx.x;
+    if (f < F && t < T) {
+      const float2 z = tile[threadIdx.x][j];
+      re[f * T + t] = (z.x - mean) * inv;
+      im[f * T + t] = (z.y - mean) * inv;
+    }
+  }
+}
+
+}  // namespace mia
+
+extern "C" {
+
+int mia_normalize_rows(const float* x, int64_t rows, int64_t n, float eps, float* out, float* stats,
+                       void* sums, void* stream) {
+  using namespace mia;
+  MIA_REQUIRE(rows >= 0 && n >= 1, "rows and n must be >= 0 and 1");
+  MIA_REQUIRE(rows <= 65535, "at most 65535 rows per call");
+  if (rows == 0) return MIA_OK;
+  MIA_REQUIRE(x && out && stats && sums, "null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  MIA_CHECK_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 2 * (size_t)rows, s));
+  // about 2048 workgroups in all: enough to fill the device, few enough that the two atomics
+  // each of them ends with do not queue up on a row's pair of sums
+  long long chunks = (n + 256 * 16 - 1) / (256 * 16);
+  const long long cap = 2048 / rows > 1 ? 2048 / rows : 1;
+  if (chunks > cap) chunks = cap;
+  const dim3 grid((unsigned)chunks, (unsigned)rows);
+  hipLaunchKernelGGL(row_moments_kernel, grid, dim3(256), 0, s, x, (long long)n, (double*)sums);
+  hipLaunchKernelGGL(row_normalize_kernel, grid, dim3(256), 0, s, x, (long long)n,
+                     (const double*)sums, eps, out, stats);
+  MIA_CHECK_HIP(hipGetLastError());
+  return MIA_OK;
+}
+
+int mia_normalize_cac(const void* spec, int64_t batch, int channels, int64_t bins, int64_t frames,
+                      int64_t stride_b, int64_t stride_c, int64_t stride_f, int64_t stride_t,
+                      float eps, float* out, float* stats, void* sums, void* stream) {
+  using namespace mia;
+  MIA_REQUIRE(batch >= 0 && channels >= 1 && bins >= 1 && frames >= 1,
+              "batch, channels, bins, frames must be >= 0, 1, 1, 1");
+  MIA_REQUIRE(batch * channels <= 65535, "at most 65535 (batch x channel) planes per call");
+  if (batch == 0) return MIA_OK;
+  MIA_REQUIRE(spec && out && stats && sums, "null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  MIA_CHECK_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 2 * (size_t)batch, s));
+  long long chunks = frames;
+  const long long cap = 2048 / (batch * channels) > 1 ? 2048 / (batch * channels) : 1;
+  if (chunks > cap) chunks = cap;
+  hipLaunchKernelGGL(cac_moments_kernel, dim3((unsigned)chunks, (unsigned)(batch * channels)),
+                     dim3(256), 0, s,
+                     (const float2*)spec, channels, (long long)bins, (long long)frames,
+                     (long long)stride_b, (long long)stride_c, (long long)stride_f,
+                     (long long)stride_t, (double*)sums);
+  const dim3 grid((unsigned)((frames + 31) / 32), (unsigned)((bins + 31) / 32),
+                  (unsigned)(batch * channels));
+  MIA_REQUIRE(grid.y <= 65535, "too many bins");
+  hipLaunchKernelGGL(cac_normalize_kernel, grid, dim3(32, 8), 0, s, (const float2*)spec, channels,
+                     (long long)bins, (long long)frames, (long long)stride_b, (long long)stride_c,
+                     (long long)stride_f, (long long)stride_t, (const double*)sums, eps, out, stats);
+  MIA_CHECK_HIP(hipGetLastError());
+  return MIA_OK;
+}
+
+}  // extern "C"

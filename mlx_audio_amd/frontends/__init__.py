@@ -2,10 +2,10 @@
 HTDemucs spec / ispec, CLAP log-mel features."""
 
 from .clap import CLAPFeatureExtractor, clap_log_mel
-from .demucs import htdemucs_ispec, htdemucs_spec
+from .demucs import htdemucs_ispec, htdemucs_normalize, htdemucs_spec
 from .whisper import compute_log_mel_spectrogram, pad_or_trim
 
 __all__ = [
-    "compute_log_mel_spectrogram", "pad_or_trim", "htdemucs_spec", "htdemucs_ispec",
+    "compute_log_mel_spectrogram", "pad_or_trim", "htdemucs_spec", "htdemucs_ispec", "htdemucs_normalize",
     "clap_log_mel", "CLAPFeatureExtractor",
 ]

@@ -7,7 +7,8 @@ import math
 
 import torch
 
-from .._runtime import as_device_f32
+from .. import _lib
+from .._runtime import as_device_f32, stream_ptr
 from ..primitives.stft import _istft_raw, _stft_raw
 
 DEMUCS_N_FFT = 4096      # reference constants/audio_processing.py:15-17
@@ -55,3 +56,40 @@ def htdemucs_ispec(m, length: int, n_fft: int = DEMUCS_N_FFT,
     y = _istft_raw(z, n_fft, hop_length, n_fft, "hann", le + n_fft, scale=math.sqrt(n_fft))
     y = y[:, n_fft // 2:n_fft // 2 + le]
     return y.reshape(B, S, C, -1)[:, :, :, pad:pad + length]
+
+
+def htdemucs_normalize(mix, spec=None, eps: float = 1e-5):
+    """Input normalisation of `HTDemucs.__call__` (model.py:206-233).
+
+    mix [B, C, T] and its spectrogram [B, C, F, Tf] (complex64, any strides; computed with
+    `htdemucs_spec` if not given) -> (freq_in, spec_mean, spec_std, mix_norm, mix_mean, mix_std):
+    freq_in [B, 2C, F, Tf] holds the real and imaginary parts as planes 2c, 2c+1, normalised by
+    the mean and standard deviation over all of a batch item's planes; mix_norm [B, C, T]
+    likewise over the item's channels and samples.  The std values include the +eps, as in the
+    reference, where they are used later to undo the normalisation (model.py:349, 367).
+    """
+    mix = as_device_f32(mix, ndim_allowed=(3,))
+    if spec is None:
+        spec = htdemucs_spec(mix)
+    if spec.dim() != 4 or spec.dtype != torch.complex64:
+        raise ValueError("spec must be a complex64 [B, C, F, Tf] tensor")
+    B, C, T = mix.shape
+    _, Cs, F, Tf = spec.shape
+    dev = mix.device
+    lib = _lib.lib()
+    freq_in = torch.empty((B, 2 * Cs, F, Tf), dtype=torch.float32, device=dev)
+    mix_norm = torch.empty_like(mix)
+    s_stats = torch.empty((B, 2), dtype=torch.float32, device=dev)
+    m_stats = torch.empty((B, 2), dtype=torch.float32, device=dev)
+    sums = torch.empty((B, 2), dtype=torch.float64, device=dev)
+    with torch.cuda.device(dev):
+        stream = stream_ptr(dev)
+        sb, sc, sf, st = spec.stride()
+        base = spec.data_ptr()
+        _lib.check(lib.mia_normalize_cac(base, B, Cs, F, Tf, sb, sc, sf, st, float(eps),
+                                         freq_in.data_ptr(), s_stats.data_ptr(), sums.data_ptr(),
+                                         stream))
+        _lib.check(lib.mia_normalize_rows(mix.data_ptr(), B, C * T, float(eps), mix_norm.data_ptr(),
+                                          m_stats.data_ptr(), sums.data_ptr(), stream))
+    return (freq_in, s_stats[:, 0].reshape(B, 1, 1, 1), s_stats[:, 1].reshape(B, 1, 1, 1),
+            mix_norm, m_stats[:, 0].reshape(B, 1, 1), m_stats[:, 1].reshape(B, 1, 1))

@@ -620,3 +620,19 @@ def clap_padded_mel(audio: np.ndarray, sample_rate: int = 48000, n_fft: int = 10
         audio = audio[:nb_max]
     mel = clap_mel(audio, sample_rate, n_fft, hop_length, n_mels, dtype=dtype)
     return np.stack([mel, mel, mel, mel], axis=0)
+
+
+def htdemucs_normalize(mix, spec, eps=1e-5):
+    """models/demucs/model.py:206-233: complex-as-channels planes (re_ch0, im_ch0, re_ch1, ...),
+    mean / population std over each batch item, std + eps; the waveform likewise."""
+    mix = np.asarray(mix, np.float32)
+    spec = np.asarray(spec, np.complex64)
+    stacked = np.stack([spec.real, spec.imag], axis=2)
+    B, C, _, F, T = stacked.shape
+    mag = stacked.reshape(B, C * 2, F, T).astype(np.float32)
+    spec_mean = np.mean(mag, axis=(1, 2, 3), keepdims=True)
+    spec_std = np.std(mag, axis=(1, 2, 3), keepdims=True) + np.float32(eps)
+    freq_in = (mag - spec_mean) / spec_std
+    mix_mean = np.mean(mix, axis=(1, 2), keepdims=True)
+    mix_std = np.std(mix, axis=(1, 2), keepdims=True) + np.float32(eps)
+    return freq_in, spec_mean, spec_std, (mix - mix_mean) / mix_std, mix_mean, mix_std

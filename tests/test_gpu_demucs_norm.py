@@ -1,0 +1,64 @@
+"""HTDemucs input normalisation (reference models/demucs/model.py:206-233) on the GPU against
+the NumPy restatement.  Tolerance 2e-5: the statistics are accumulated in double here and in
+float32 (pairwise) there."""
+
+import numpy as np
+import pytest
+import torch
+
+import oracle.spectral as o
+from mlx_audio_amd import _lib
+from mlx_audio_amd.frontends import htdemucs_normalize, htdemucs_spec
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(a, gpu):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(gpu)
+
+
+@pytest.mark.parametrize("B,C,T", [(1, 2, 44100), (3, 2, 30000), (2, 1, 5000)])
+def test_normalisation_of_mix_and_spectrogram(gpu, B, C, T):
+    rng = np.random.default_rng(B * 10 + C)
+    mix = (0.1 * rng.standard_normal((B, C, T)) + 0.02).astype(np.float32)
+    mix *= np.arange(1, B + 1, dtype=np.float32)[:, None, None]      # different scale per item
+    md = _dev(mix, gpu)
+    spec = htdemucs_spec(md)                                          # strided view, as the model passes it
+    got = htdemucs_normalize(md, spec)
+    want = o.htdemucs_normalize(mix, spec.cpu().numpy())
+    for g, w, name in zip(got, want, ("freq_in", "spec_mean", "spec_std", "mix_norm", "mix_mean", "mix_std")):
+        assert tuple(g.shape) == w.shape, name
+        np.testing.assert_allclose(g.cpu().numpy(), w, rtol=2e-5, atol=2e-5, err_msg=name)
+    freq_in = got[0]
+    assert freq_in.shape == (B, 2 * C, 2048, int(np.ceil(T / 1024)))
+    # each item ends up with zero mean and unit deviation
+    flat = freq_in.reshape(B, -1)
+    assert flat.mean(dim=1).abs().max().item() < 1e-4
+    assert (flat.std(dim=1, unbiased=False) - 1).abs().max().item() < 1e-3
+    # the default computes the spectrogram itself
+    again = htdemucs_normalize(md)
+    assert torch.equal(again[0], freq_in)
+
+
+def test_contiguous_spectrogram_odd_tile_sizes_and_c_abi(gpu):
+    rng = np.random.default_rng(5)
+    spec = (rng.standard_normal((2, 3, 45, 70)) + 1j * rng.standard_normal((2, 3, 45, 70))).astype(np.complex64)
+    mix = rng.standard_normal((2, 3, 777)).astype(np.float32)
+    got = htdemucs_normalize(_dev(mix, gpu), _dev(spec, gpu))
+    want = o.htdemucs_normalize(mix, spec)
+    for g, w in zip(got, want):
+        np.testing.assert_allclose(g.cpu().numpy(), w, rtol=2e-5, atol=2e-5)
+    with pytest.raises(ValueError, match="complex64"):
+        htdemucs_normalize(_dev(mix, gpu), _dev(spec.real.copy(), gpu))
+    lib = _lib.lib()
+    x = torch.ones(8, device=gpu)
+    sums = torch.zeros(4, dtype=torch.float64, device=gpu)
+    s = torch.cuda.current_stream(gpu).cuda_stream
+    assert lib.mia_normalize_rows(x.data_ptr(), 1, 0, 1e-5, x.data_ptr(), x.data_ptr(), sums.data_ptr(), s) == _lib.MIA_ERR_INVALID
+    assert lib.mia_normalize_rows(x.data_ptr(), 70000, 1, 1e-5, x.data_ptr(), x.data_ptr(), sums.data_ptr(), s) == _lib.MIA_ERR_INVALID
+    out = torch.empty(8, device=gpu)
+    st = torch.empty(2, device=gpu)
+    assert lib.mia_normalize_rows(x.data_ptr(), 1, 8, 1e-5, out.data_ptr(), st.data_ptr(), sums.data_ptr(), s) == _lib.MIA_OK
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out.cpu().numpy(), 0.0)               # a constant row: (1 - 1) / (0 + eps)
+    np.testing.assert_allclose(st.cpu().numpy(), [1.0, 1e-5], rtol=1e-6)
