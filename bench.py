@@ -16,6 +16,7 @@ Workloads (config.workload):
   resample_fft 64 x 30 s @44.1 kHz -> 16 kHz, Fourier method (the reference's default)
   features    centroid + bandwidth + roll-off + flatness of a (512, 1025, 938) spectrogram
   contrast    spectral contrast of the same spectrogram
+  features_y  the four statistics from 512 x 30 s waveforms in one launch (fused epilogue)
   onset       onset strength of 4096 mel spectrograms (128 x 938)
   griffinlim  8 Griffin-Lim iterations on 64 x 10 s @22.05 kHz, n_fft 2048 / hop 512
   spectral_gate  spectral gating of 64 x 10 s @22.05 kHz
@@ -169,6 +170,16 @@ def make_workload(name: str, clips: int, device, seed: int):
                 f"HTDemucs model input: spectrogram (n_fft 4096, hop 1024) + complex-as-channels "
                 f"normalisation + waveform normalisation, {clips} stereo x 60 s @44.1 kHz",
                 "HTDemucs front-end track-hours/sec")
+    if name == "features_y":
+        from mlx_audio_amd.primitives import fused_statistics
+
+        T = 480000
+        y = torch.randn((clips, T), generator=gen, device=device, dtype=torch.float32)
+        abytes = clips * (T * 4 + 4 * 938 * 4)
+        return (lambda: fused_statistics(y, sr=16000, n_fft=2048, hop_length=512),
+                clips * 30.0 / 3600.0, abytes,
+                f"centroid + bandwidth + roll-off + flatness from the waveform in one launch, "
+                f"{clips} x 30 s @16 kHz, n_fft 2048 hop 512", "spectral features (from audio) audio-hours/sec")
     raise SystemExit(f"unknown workload {name}")
 
 
@@ -183,6 +194,7 @@ KERNEL_OF = {
     "spectral_gate": "fwd_kernel<2048> + magnitude/phase + 9 mask kernels + polar + istft_kernel<2048>",
     "griffinlim": "per iteration istft_kernel<2048> + fwd_kernel<2048> + griffinlim_update_kernel",
     "onset": "onset_flux_shift_kernel (a wave per 64 frames, lagged values by lane shift)",
+    "features_y": "fwd_kernel<2048> with the statistics epilogue (no spectrogram in memory)",
     "features": "spectral_stat_kernel x 4 (one thread per frame, bins walked in order)",
     "resample_fft": "stockham_pass_kernel<16> x 22 + chirp / spectrum kernels (two chirp-z "
                     "convolutions per clip)",
@@ -281,7 +293,7 @@ def main() -> None:
               "torch.distributed.run for N>1", file=sys.stderr)
 
     default_clips = {"whisper128": 1024, "clap64": 1024, "mfcc40": 1024, "htdemucs": 32,
-                     "resample": 512, "resample_fft": 64, "features": 512, "contrast": 512, "onset": 4096, "griffinlim": 64, "spectral_gate": 64, "demucs_front": 16}
+                     "resample": 512, "resample_fft": 64, "features": 512, "contrast": 512, "onset": 4096, "griffinlim": 64, "spectral_gate": 64, "demucs_front": 16, "features_y": 512}
     clips = args.clips or default_clips.get(args.workload, 1024)
     step, units, abytes, desc, metric = make_workload(args.workload, clips, device, 1234 + rank)
 

@@ -247,6 +247,15 @@ int mia_resample_fft(const float* x, int64_t rows, int64_t n_in, int64_t n_out, 
 int mia_spectral_stat(const float* S, int64_t rows, int bins, int64_t frames, const float* freq,
                       const float* aux, int mode, float p, int norm, float fraction, float amin,
                       float power, float* out, void* stream);
+/* The four statistics straight from the waveform, one launch and no spectrogram in memory:
+ * the forward kernel (pad, frame, window, FFT, magnitude) with the statistics as its epilogue
+ * (features.py:26-56 + :59-464 for y given).  plan: any plan (its mel / DCT stages are not
+ * used); freq: device (n_fft/2 + 1); out: device (B, 4, frames) = centroid, bandwidth
+ * (exponent p_exp, normalised if norm), roll-off (roll_percent), flatness (of
+ * max(magnitude^flat_power, flat_amin)). */
+int mia_spectral_stats(const mia_plan* plan, const float* y, int64_t B, int64_t T, const float* freq,
+                       float p_exp, int norm, float roll_percent, float flat_power, float flat_amin,
+                       float* out, void* stream);
 /* spectral_contrast (features.py:467-639; _ext.spectral_contrast): S as above; bands: device
  * int32 (n_bands_out, 3) = {first bin, one past the last bin, values averaged at each end} per
  * octave band, built by the caller from the bin frequencies as the reference does

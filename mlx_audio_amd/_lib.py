@@ -88,6 +88,8 @@ SIGNATURES = {
                                     c_void_p, c_void_p]),
     "mia_spectral_stat": (c_int, [c_void_p, c_int64, c_int, c_int64, c_void_p, c_void_p, c_int,
                                   c_float, c_int, c_float, c_float, c_float, c_void_p, c_void_p]),
+    "mia_spectral_stats": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_float, c_int,
+                                   c_float, c_float, c_float, c_void_p, c_void_p]),
     "mia_spectral_contrast": (c_int, [c_void_p, c_int64, c_int, c_int64, c_void_p, c_int, c_int,
                                       c_int, c_void_p, c_void_p]),
     "mia_zero_crossing_rate": (c_int, [c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_int,

@@ -673,6 +673,29 @@ int mia_melspectrogram(const mia_plan* plan, const float* y, int64_t B, int64_t 
                      workspace_bytes, (hipStream_t)stream);
 }
 
+int mia_spectral_stats(const mia_plan* plan, const float* y, int64_t B, int64_t T, const float* freq,
+                       float p_exp, int norm, float roll_percent, float flat_power, float flat_amin,
+                       float* out, void* stream) {
+  FwdParams p;
+  int rc = fill_fwd(plan, y, B, T, p);
+  if (rc != MIA_OK) return rc;
+  MIA_REQUIRE(freq != nullptr && (out != nullptr || B == 0), "null pointer");
+  MIA_REQUIRE(p_exp > 0.0f && roll_percent >= 0.0f && roll_percent <= 1.0f,
+              "p must be > 0 and roll_percent in [0, 1]");
+  p.n_mels = 4;  // rows of the output per clip
+  p.power_mode = 1;  // magnitudes in the LDS tile
+  p.power = 1.0f;
+  p.mout = out;
+  p.epi = kEpiStats;
+  p.freq = freq;
+  p.stat_p = p_exp;
+  p.stat_norm = norm;
+  p.stat_roll = roll_percent;
+  p.flat_power = flat_power;
+  p.flat_amin = flat_amin;
+  return launch_forward(plan, p, 2, (hipStream_t)stream);
+}
+
 size_t mia_mfcc_workspace_bytes(const mia_plan* plan, int64_t B, int64_t T) {
   if (!plan || B <= 0) return 0;
   const int64_t F = mia_plan_num_frames(plan, T);

@@ -126,7 +126,15 @@ struct FwdParams {
   int* clip_max_key;   // B (+1) keys of the per-clip maximum, or nullptr
   int* clip_min_key;   // B keys of the per-clip minimum of the stored values
   int dbg;
+  // spectral-statistics epilogue (epi == kEpiStats): centroid, bandwidth, roll-off, flatness
+  const float* freq;   // bin frequencies
+  float stat_p;        // bandwidth exponent
+  int stat_norm;       // bandwidth normalised by the magnitude sum
+  float stat_roll;     // roll-off fraction
+  float flat_power;    // flatness is taken of magnitude^flat_power ...
+  float flat_amin;     // ... floored here
 };
+constexpr int kEpiStats = 3;  // internal epilogue code (the public ones are MIA_EPI_*)
 
 struct W400Tables {
   const float* win16;

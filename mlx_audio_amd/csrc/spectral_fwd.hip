@@ -425,6 +425,87 @@ __global__ __launch_bounds__(WG, 2) void fwd_kernel(FwdParams p) {
     }
   }
 
+  if constexpr (MODE == 2) {
+    __syncthreads();
+    const long long frem2 = p.F - f0;
+    const int fcount = frem2 < FT ? (int)frem2 : FT;
+    {
+      // Spectral statistics of the tile's frames straight from the magnitude rows in LDS:
+      // a wave per frame, every lane a contiguous run of bins (odd run lengths and the odd row
+      // pitch keep the reads conflict-free), wave reductions for the sums and a wave scan for
+      // the roll-off point.  out: (B, 4, F) = centroid, bandwidth, roll-off, flatness.
+      constexpr int BINS = M + 1;
+      constexpr int RUN = ((BINS + 63) / 64) | 1;
+      const int lane = tid & 63;
+      const int k0 = lane * RUN < BINS ? lane * RUN : BINS;
+      const int k1 = k0 + RUN < BINS ? k0 + RUN : BINS;
+      for (int fl = tid >> 6; fl < fcount; fl += WG / 64) {
+        const float* __restrict__ pr = P + fl * PS;
+        float ts = 0.0f, ws = 0.0f, ls = 0.0f, as = 0.0f;
+        for (int k = k0; k < k1; ++k) {
+          const float v = pr[k];
+          ts += v;
+          ws += p.freq[k] * v;
+          float u = p.flat_power == 2.0f ? v * v : (p.flat_power == 1.0f ? v : powf(v, p.flat_power));
+          u = u < p.flat_amin ? p.flat_amin : u;
+          ls += logf(u);
+          as += u;
+        }
+        float incl = ts;  // inclusive scan of the lanes' sums
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+          const float t = __shfl_up(incl, off);
+          if (lane >= off) incl += t;
+        }
+        const float excl = incl - ts;
+        const float total = __shfl(incl, 63);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+          ws += __shfl_xor(ws, off);
+          ls += __shfl_xor(ls, off);
+          as += __shfl_xor(as, off);
+        }
+        const float centroid = ws / (total + 1e-8f);
+        float bw = 0.0f;
+        for (int k = k0; k < k1; ++k) {
+          const float d = fabsf(p.freq[k] - centroid);
+          const float dp = p.stat_p == 2.0f ? d * d : (p.stat_p == 1.0f ? d : powf(d, p.stat_p));
+          bw += pr[k] * dp;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) bw += __shfl_xor(bw, off);
+        if (p.stat_norm) bw = bw / (total + 1e-8f);
+        bw = p.stat_p == 2.0f ? sqrtf(bw) : (p.stat_p == 1.0f ? bw : powf(bw, 1.0f / p.stat_p));
+        // roll-off: the first lane whose running sum reaches the threshold finds the bin
+        const float thr = p.stat_roll * total;
+        const unsigned long long reached = __ballot(incl >= thr && k1 > k0);
+        int bin = BINS - 1;
+        if (reached != 0ULL) {
+          const int first = __ffsll((long long)reached) - 1;
+          int mine = k1 - 1;
+          if (lane == first) {
+            float cs = excl;
+            for (int k = k0; k < k1; ++k) {
+              cs += pr[k];
+              if (cs >= thr) {
+                mine = k;
+                break;
+              }
+            }
+          }
+          bin = __shfl(mine, first);
+        }
+        if (lane == 0) {
+          float* __restrict__ o = p.mout + (b * 4) * p.F + f0 + fl;
+          o[0] = centroid;
+          o[p.F] = bw;
+          o[2 * p.F] = p.freq[bin];
+          o[3 * p.F] = expf(ls / (float)BINS) / (as / (float)BINS + 1e-8f);
+        }
+      }
+    }
+    __syncthreads();  // the next tile overwrites the magnitude rows
+  }
   if constexpr (MODE == 1) {
     __syncthreads();
     const long long frem = p.F - f0;
@@ -510,7 +591,7 @@ static int launch_cfg(const FwdParams& p0, hipStream_t s) {
   constexpr int PS = (C::M + 1) | 1;
   FwdParams p = p0;
   p.tiles = (int)((p.F + FT - 1) / FT);
-  size_t lds = sizeof(float2) * G * C::LBUF + (MODE == 1 ? sizeof(float) * FT * PS : 0);
+  size_t lds = sizeof(float2) * G * C::LBUF + (MODE != 0 ? sizeof(float) * FT * PS : 0);
   if (MODE == 1) {
     // band tables ride along in LDS when two workgroups still fit a CU
     const size_t tables = sizeof(float) * (size_t)p.nnz + 3 * sizeof(int) * (size_t)p.n_mels;
@@ -519,7 +600,7 @@ static int launch_cfg(const FwdParams& p0, hipStream_t s) {
       p.lds_tables = 1;
     }
   }
-  static_assert(sizeof(float2) * G * C::LBUF + (MODE == 1 ? sizeof(float) * FT * PS : 0) <=
+  static_assert(sizeof(float2) * G * C::LBUF + (MODE != 0 ? sizeof(float) * FT * PS : 0) <=
                     160 * 1024,
                 "LDS budget");
   const long long total = p.B * p.tiles;
@@ -604,7 +685,8 @@ int forward_tile_frames(int n_fft, int /*mode*/) {
 }
 
 int launch_forward(const mia_plan* plan, const FwdParams& p, int mode, hipStream_t s) {
-  return mode == 0 ? dispatch_mode<0>(plan->n_fft, p, s) : dispatch_mode<1>(plan->n_fft, p, s);
+  if (mode == 0) return dispatch_mode<0>(plan->n_fft, p, s);
+  return mode == 1 ? dispatch_mode<1>(plan->n_fft, p, s) : dispatch_mode<2>(plan->n_fft, p, s);
 }
 
 }  // namespace mia

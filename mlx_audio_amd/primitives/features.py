@@ -12,8 +12,9 @@ import numpy as np
 import torch
 
 from .. import _lib
-from .._runtime import as_device_f32, require_gpu, stream_ptr
-from .stft import magnitude, stft
+from .._runtime import as_device_f32, get_plan, require_gpu, stream_ptr
+from .stft import _resolve, magnitude, stft
+from .windows import padded_window_np
 
 _STAT = {"centroid": 0, "bandwidth": 1, "rolloff": 2, "flatness": 3}
 
@@ -51,6 +52,43 @@ def _default_freq_dev(sr, n_fft: int, device) -> torch.Tensor:
         t = torch.from_numpy(_get_frequencies(sr, n_fft)).to(device)
         _freq_dev_cache[key] = t
     return t
+
+
+def fused_statistics(y, sr: int = 22050, n_fft: int = 2048, hop_length: int = 512, win_length=None,
+                     window="hann", center: bool = True, pad_mode: str = "constant", p: float = 2.0,
+                     norm: bool = True, roll_percent: float = 0.85, power: float = 2.0,
+                     amin: float = 1e-10):
+    """Centroid, bandwidth, roll-off and flatness of a waveform in one launch: the forward STFT
+    kernel with the statistics as its epilogue, so no spectrogram reaches memory.  Returns a
+    (4, frames) or (batch, 4, frames) tensor in that order.  No counterpart function in the
+    reference (its four functions each compute their own spectrogram, features.py:26-56); the
+    four mirror functions below use it whenever they are called with a waveform."""
+    hop_length, win_length = _resolve(n_fft, hop_length, win_length)
+    if center and pad_mode not in _lib.PAD_MODES:
+        raise ValueError(f"Unknown pad_mode: '{pad_mode}'. Supported: reflect, constant, edge")
+    x = as_device_f32(y)
+    is_1d = x.dim() == 1
+    xb = x[None] if is_1d else x
+    win = padded_window_np(window, win_length, n_fft)
+    plan = get_plan(xb.device, n_fft, hop_length, center, pad_mode if center else "constant", win)
+    B, T = xb.shape
+    frames = plan.num_frames(T)
+    freq = _default_freq_dev(sr, n_fft, xb.device)
+    out = torch.empty((B, 4, frames), dtype=torch.float32, device=xb.device)
+    with torch.cuda.device(xb.device):
+        _lib.check(_lib.lib().mia_spectral_stats(
+            plan.handle, xb.data_ptr(), B, T, freq.data_ptr(), float(p), int(bool(norm)),
+            float(roll_percent), float(power), float(amin), out.data_ptr(), stream_ptr(xb.device)))
+    return out[0] if is_1d else out
+
+
+def _fused_ok(y, S, freq, n_fft) -> bool:
+    return (S is None and y is not None and freq is None
+            and bool(_lib.lib().mia_fft_size_supported(int(n_fft))))
+
+
+def _pick(stats: torch.Tensor, which: int) -> torch.Tensor:
+    return stats[..., which:which + 1, :]
 
 
 def _dev_vector(v, device) -> torch.Tensor:
@@ -92,6 +130,8 @@ def spectral_centroid(y=None, sr: int = 22050, S=None, n_fft: int = 2048, hop_le
                       win_length=None, window="hann", center: bool = True,
                       pad_mode: str = "constant", freq=None) -> torch.Tensor:
     """Centre of mass of the spectrum per frame (reference features.py:59-136)."""
+    if _fused_ok(y, S, freq, n_fft):
+        return _pick(fused_statistics(y, sr, n_fft, hop_length, win_length, window, center, pad_mode), 0)
     S = _compute_spectrogram(y, S, n_fft, hop_length, win_length, window, center, pad_mode)
     if freq is None:
         freq = _default_freq_dev(sr, n_fft, S.device)
@@ -103,6 +143,9 @@ def spectral_bandwidth(y=None, sr: int = 22050, S=None, n_fft: int = 2048, hop_l
                        pad_mode: str = "constant", freq=None, centroid=None, p: float = 2.0,
                        norm: bool = True) -> torch.Tensor:
     """Spread of the spectrum around its centroid (reference features.py:139-241)."""
+    if centroid is None and _fused_ok(y, S, freq, n_fft):
+        return _pick(fused_statistics(y, sr, n_fft, hop_length, win_length, window, center, pad_mode,
+                                      p=p, norm=norm), 1)
     S = _compute_spectrogram(y, S, n_fft, hop_length, win_length, window, center, pad_mode)
     if freq is None:
         freq = _default_freq_dev(sr, n_fft, S.device)
@@ -121,6 +164,9 @@ def spectral_rolloff(y=None, sr: int = 22050, S=None, n_fft: int = 2048, hop_len
         raise ValueError(f"roll_percent must be >= 0.0, got {roll_percent}")
     if roll_percent > 1.0:
         raise ValueError(f"roll_percent must be <= 1.0, got {roll_percent}")
+    if _fused_ok(y, S, freq, n_fft):
+        return _pick(fused_statistics(y, sr, n_fft, hop_length, win_length, window, center, pad_mode,
+                                      roll_percent=roll_percent), 2)
     S = _compute_spectrogram(y, S, n_fft, hop_length, win_length, window, center, pad_mode)
     if freq is None:
         freq = _default_freq_dev(sr, n_fft, S.device)
@@ -132,6 +178,9 @@ def spectral_flatness(y=None, S=None, n_fft: int = 2048, hop_length: int = 512, 
                       power: float = 2.0, amin: float = 1e-10) -> torch.Tensor:
     """Wiener entropy per frame (reference features.py:385-464).  `power` applies to the
     magnitude computed from `y`; a spectrogram passed as `S` is used as it is."""
+    if _fused_ok(y, S, None, n_fft):
+        return _pick(fused_statistics(y, 22050, n_fft, hop_length, win_length, window, center, pad_mode,
+                                      power=power, amin=amin), 3)
     from_y = S is None
     S = _compute_spectrogram(y, S, n_fft, hop_length, win_length, window, center, pad_mode)
     return _stat(S, "flatness", amin=amin, power=power if from_y else 1.0)

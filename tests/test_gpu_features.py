@@ -10,7 +10,7 @@ import torch
 
 import oracle.features as orc
 from mlx_audio_amd import _lib
-from mlx_audio_amd.primitives import (spectral_bandwidth, spectral_centroid, spectral_contrast,
+from mlx_audio_amd.primitives import (fused_statistics, magnitude, stft, spectral_bandwidth, spectral_centroid, spectral_contrast,
                                       spectral_flatness, spectral_rolloff, zero_crossing_rate)
 
 pytestmark = pytest.mark.gpu
@@ -135,6 +135,34 @@ def test_spectral_contrast_from_a_waveform_and_limits(gpu):
     S = _spec(rng, (1, 4097, 5))   # 0.2 of the 2800-bin top band is far more than 64 values
     with pytest.raises(NotImplementedError, match="exceed the supported 64"):
         spectral_contrast(S=_dev(S, gpu), sr=44100, n_fft=8192, quantile=0.2)
+
+
+@pytest.mark.parametrize("n_fft,hop", [(2048, 512), (1024, 256), (400, 160), (512, 128), (4096, 1024), (256, 64), (800, 200)])
+def test_fused_statistics_equal_the_spectrogram_path(gpu, n_fft, hop):
+    """The statistics as an epilogue of the forward kernel against the same statistics of the
+    materialised magnitude spectrogram (same magnitudes; only the summation order differs)."""
+    rng = np.random.default_rng(n_fft + hop)
+    t = np.arange(30000) / 22050.0
+    y = np.stack([np.sin(2 * np.pi * 900 * t) + 0.2 * rng.standard_normal(30000),
+                  rng.standard_normal(30000), 0.01 * rng.standard_normal(30000)]).astype(np.float32)
+    yd = _dev(y, gpu)
+    S = magnitude(stft(yd, n_fft=n_fft, hop_length=hop))
+    kw = dict(sr=22050, n_fft=n_fft)
+    for p_exp, norm, roll, power in ((2.0, True, 0.85, 2.0), (1.0, False, 0.5, 1.0), (3.0, True, 0.99, 2.0)):
+        got = fused_statistics(yd, hop_length=hop, p=p_exp, norm=norm, roll_percent=roll, power=power, **kw)
+        assert got.shape == (3, 4, S.shape[-1])
+        c = spectral_centroid(S=S, **kw)
+        torch.testing.assert_close(got[:, 0:1], c, rtol=3e-5, atol=1e-2)
+        torch.testing.assert_close(got[:, 1:2], spectral_bandwidth(S=S, p=p_exp, norm=norm, **kw), rtol=1e-4, atol=1e-2)
+        r = spectral_rolloff(S=S, roll_percent=roll, **kw)
+        step = 22050 / n_fft
+        assert (got[:, 2:3] - r).abs().max().item() <= step * 1.001
+        assert ((got[:, 2:3] != r).float().mean().item()) <= 0.03
+        fl = spectral_flatness(S=S ** power if power != 1.0 else S)
+        torch.testing.assert_close(got[:, 3:4], fl, rtol=2e-4, atol=1e-9)
+    one = fused_statistics(yd[0], hop_length=hop, **kw)
+    assert one.shape == (4, S.shape[-1])
+    torch.testing.assert_close(one, fused_statistics(yd, hop_length=hop, **kw)[0], rtol=0, atol=0)
 
 
 def test_short_signals_and_c_abi_checks(gpu):
