@@ -185,6 +185,11 @@ int mia_dct2(const float* x, int64_t outer, int n_in, int64_t inner, const float
 /* |z| and atan2(im, re) of n complex64 values (primitives/stft.py:347-379). */
 int mia_magnitude(const void* z, int64_t n, float* out, void* stream);
 int mia_phase(const void* z, int64_t n, float* out, void* stream);
+/* The same (op 0: |z|, op 1: atan2) for the spectrum as mia_stft writes it, (rows, frames, bins),
+ * delivered in the order the reference's stft / magnitude / phase return, (rows, bins, frames):
+ * magnitude(stft(y)) without the transposing copy in between. */
+int mia_spectrum_part(const void* z, int64_t rows, int64_t frames, int64_t bins, int op, float* out,
+                      void* stream);
 
 /* ---- sample-rate conversion (primitives/resample.py) -------------------------------
  * Padding modes of the polyphase filter (the `padtype` values of resample_poly,

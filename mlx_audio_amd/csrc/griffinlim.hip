@@ -42,9 +42,52 @@ __global__ __launch_bounds__(256) void griffinlim_update_kernel(const float2* __
   rebuilt[i] = o;
 }
 
+// |z| or arg z of a spectrum held as (rows, frames, bins) — the order the STFT kernel writes —
+// delivered as (rows, bins, frames), the order the reference's functions return: 32 x 32 tiles
+// through LDS, read with bins fastest, written with frames fastest.  grid (tiles over frames,
+// tiles over bins, rows), block (32, 8).
+__global__ __launch_bounds__(256) void spectrum_part_kernel(const float2* __restrict__ z,
+                                                            long long F, long long bins, int op,
+                                                            float* __restrict__ out) {
+  __shared__ float tile[32][33];
+  const long long row = blockIdx.z;
+  const long long f0 = (long long)blockIdx.x * 32, k0 = (long long)blockIdx.y * 32;
+  const float2* __restrict__ src = z + row * F * bins;
+  for (int j = threadIdx.y; j < 32; j += 8) {  // j: frame in the tile, x: bin
+    const long long f = f0 + j, k = k0 + threadIdx.x;
+    float v = 0.0f;
+    if (f < F && k < bins) {
+      const float2 c = src[f * bins + k];
+      v = op == 0 ? hypotf(c.x, c.y) : atan2f(c.y, c.x);
+    }
+    tile[j][threadIdx.x] = v;
+  }
+  __syncthreads();
+  float* __restrict__ dst = out + row * bins * F;
+  for (int j = threadIdx.y; j < 32; j += 8) {  // j: bin in the tile, x: frame
+    const long long k = k0 + j, f = f0 + threadIdx.x;
+    if (f < F && k < bins) dst[k * F + f] = tile[threadIdx.x][j];
+  }
+}
+
 }  // namespace mia
 
 extern "C" {
+
+int mia_spectrum_part(const void* z, int64_t rows, int64_t frames, int64_t bins, int op, float* out,
+                      void* stream) {
+  using namespace mia;
+  MIA_REQUIRE(rows >= 0 && frames >= 0 && bins >= 0, "negative shape");
+  MIA_REQUIRE(op == 0 || op == 1, "op must be 0 (magnitude) or 1 (phase)");
+  if (rows == 0 || frames == 0 || bins == 0) return MIA_OK;
+  MIA_REQUIRE(z && out, "null pointer");
+  MIA_REQUIRE(rows <= 65535 && (bins + 31) / 32 <= 65535, "at most 65535 rows per call");
+  const dim3 grid((unsigned)((frames + 31) / 32), (unsigned)((bins + 31) / 32), (unsigned)rows);
+  hipLaunchKernelGGL(spectrum_part_kernel, grid, dim3(32, 8), 0, (hipStream_t)stream,
+                     (const float2*)z, (long long)frames, (long long)bins, op, out);
+  MIA_CHECK_HIP(hipGetLastError());
+  return MIA_OK;
+}
 
 int mia_polar(const float* mag, const float* angle, int64_t n, void* out, void* stream) {
   using namespace mia;

@@ -115,7 +115,7 @@ def spectral_gate(audio, noise_profile=None, *, sr: int = 22050, n_fft: int = 20
         x = x[None]
     n_samples = x.shape[-1]
     kw = dict(n_fft=n_fft, hop_length=hop_length, win_length=win_length, window=window, center=True)
-    C = stft(x, **kw).contiguous()   # (rows, bins, frames) in memory: one transposing copy, not two
+    C = stft(x, **kw)   # magnitude / phase transpose it to (rows, bins, frames) as they go
     mag, ph = magnitude(C), phase(C)
     ops = _Ops(mag.device)
     rows, bins, frames = mag.shape
@@ -167,7 +167,7 @@ def spectral_gate_adaptive(audio, *, sr: int = 22050, n_fft: int = 2048, hop_len
     if is_1d:
         x = x[None]
     n_samples = x.shape[-1]
-    C = stft(x, n_fft=n_fft, hop_length=hop_length, center=True).contiguous()
+    C = stft(x, n_fft=n_fft, hop_length=hop_length, center=True)
     mag, ph = magnitude(C), phase(C)
     ops = _Ops(mag.device)
     floor = ops.time_min(mag, ahead + back + 1)

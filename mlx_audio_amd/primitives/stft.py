@@ -142,7 +142,21 @@ def istft(stft_matrix, hop_length=None, win_length=None, n_fft=None, window="han
 def _complex_elementwise(fn_name: str, stft_matrix: torch.Tensor) -> torch.Tensor:
     require_gpu()
     z = stft_matrix if stft_matrix.is_cuda else stft_matrix.to("cuda")
-    z = z.to(torch.complex64).contiguous()
+    z = z.to(torch.complex64)
+    # What `stft` returns is a (.., bins, frames) view of a (.., frames, bins) buffer: transpose
+    # while taking the magnitude / phase instead of copying the complex spectrum first.
+    if z.dim() in (2, 3) and z.numel() > 0 and not z.is_contiguous():
+        zt = z.transpose(-1, -2)
+        rows = 1 if z.dim() == 2 else z.shape[0]
+        if zt.is_contiguous() and rows <= 65535:
+            frames, bins = zt.shape[-2], zt.shape[-1]
+            out = torch.empty(z.shape, dtype=torch.float32, device=z.device)
+            with torch.cuda.device(z.device):
+                _lib.check(_lib.lib().mia_spectrum_part(
+                    zt.data_ptr(), rows, frames, bins, 0 if fn_name == "mia_magnitude" else 1,
+                    out.data_ptr(), stream_ptr(z.device)))
+            return out
+    z = z.contiguous()
     out = torch.empty(z.shape, dtype=torch.float32, device=z.device)
     with torch.cuda.device(z.device):
         _lib.check(getattr(_lib.lib(), fn_name)(z.data_ptr(), z.numel(), out.data_ptr(),

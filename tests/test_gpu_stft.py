@@ -242,3 +242,25 @@ def test_fused_istft_equals_two_kernel_path(gpu, n_fft, B, F):
             _lib.check(lib.mia_istft(plan.handle, spec.data_ptr(), B, F, sb, sk, sf, out_len, 0.5,
                                      got.data_ptr(), None, 0, stream_ptr(spec.device)))
         assert torch.equal(got, ref), (out_len, float((got - ref).abs().max()))
+
+
+@pytest.mark.gpu
+def test_magnitude_and_phase_of_the_stft_view_skip_the_copy(gpu):
+    """magnitude / phase of the strided view `stft` returns (transposing kernel) equal the same
+    functions on a contiguous copy (elementwise kernel) bit for bit, for batched and 1-D input
+    and tile-unfriendly sizes."""
+    import torch
+
+    from mlx_audio_amd.primitives import magnitude, phase, stft
+
+    g = torch.Generator(device=gpu)
+    g.manual_seed(0)
+    for shape, n_fft, hop in (((3, 9000), 512, 128), ((7001,), 400, 160), ((2, 50000), 2048, 512)):
+        y = torch.randn(shape, generator=g, device=gpu)
+        C = stft(y, n_fft=n_fft, hop_length=hop)
+        assert not C.is_contiguous()
+        for fn in (magnitude, phase):
+            a = fn(C)
+            b = fn(C.contiguous())
+            assert a.shape == C.shape and a.is_contiguous()
+            assert torch.equal(a, b)
