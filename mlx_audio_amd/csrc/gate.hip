@@ -49,12 +49,14 @@ __global__ __launch_bounds__(256) void noise_threshold_kernel(const float* __res
 }
 
 // out[r, i] = min of x[r, clamp(j)] over j in [i - size/2, i + (size-1)/2]
+template <class Index>
 __global__ __launch_bounds__(256) void time_min_filter_kernel(const float* __restrict__ x,
                                                               long long rows, long long n, int size,
                                                               float* __restrict__ out) {
   const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= rows * n) return;
-  const long long r = g / n, i = g - r * n;
+  const Index rq = (Index)g / (Index)n;
+  const long long r = (long long)rq, i = g - r * n;
   const float* __restrict__ line = x + r * n;
   float m = INFINITY;
   for (long long j = i - size / 2; j <= i + (size - 1) / 2; ++j) {
@@ -66,15 +68,18 @@ __global__ __launch_bounds__(256) void time_min_filter_kernel(const float* __res
 
 // Moving average along the middle axis of x viewed as (outer, n, inner), window
 // [i - size/2, i + (size-1)/2] with indices clamped to the ends; the sum runs in double.
+template <class Index>  // unsigned when the element count fits 32 bits: index division is most of the cost
 __global__ __launch_bounds__(256) void box_filter_kernel(const float* __restrict__ x,
                                                          long long outer, long long n,
                                                          long long inner, int size,
                                                          float* __restrict__ out) {
   const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= outer * n * inner) return;
-  const long long in = g % inner;
-  const long long i = (g / inner) % n;
-  const long long o = g / (inner * n);
+  const Index gi = (Index)g, q1 = gi / (Index)inner;
+  const long long in = (long long)(gi - q1 * (Index)inner);
+  const Index q2 = q1 / (Index)n;
+  const long long i = (long long)(q1 - q2 * (Index)n);
+  const long long o = (long long)q2;
   const float* __restrict__ line = x + o * n * inner + in;
   double sum = 0.0;
   for (long long j = i - size / 2; j <= i + (size - 1) / 2; ++j) {
@@ -152,8 +157,13 @@ int mia_time_min_filter(const float* x, int64_t rows, int64_t n, int size, float
   MIA_REQUIRE(rows >= 0 && n >= 0 && size >= 1, "rows, n, size must be >= 0, 0, 1");
   if (rows == 0 || n == 0) return MIA_OK;
   MIA_REQUIRE(x && out && x != out, "null or aliased pointers");
-  hipLaunchKernelGGL(time_min_filter_kernel, dim3(gate_blocks(rows * n)), dim3(256), 0,
-                     (hipStream_t)stream, x, (long long)rows, (long long)n, size, out);
+  if ((long long)rows * n < (1LL << 31)) {
+    hipLaunchKernelGGL(time_min_filter_kernel<unsigned>, dim3(gate_blocks(rows * n)), dim3(256), 0,
+                       (hipStream_t)stream, x, (long long)rows, (long long)n, size, out);
+  } else {
+    hipLaunchKernelGGL(time_min_filter_kernel<unsigned long long>, dim3(gate_blocks(rows * n)),
+                       dim3(256), 0, (hipStream_t)stream, x, (long long)rows, (long long)n, size, out);
+  }
   MIA_CHECK_HIP(hipGetLastError());
   return MIA_OK;
 }
@@ -165,9 +175,15 @@ int mia_box_filter(const float* x, int64_t outer, int64_t n, int64_t inner, int 
               "outer, n, inner, size must be >= 0, 0, 0, 1");
   if (outer == 0 || n == 0 || inner == 0) return MIA_OK;
   MIA_REQUIRE(x && out && x != out, "null or aliased pointers");
-  hipLaunchKernelGGL(box_filter_kernel, dim3(gate_blocks(outer * n * inner)), dim3(256), 0,
-                     (hipStream_t)stream, x, (long long)outer, (long long)n, (long long)inner, size,
-                     out);
+  if ((long long)outer * n * inner < (1LL << 31)) {
+    hipLaunchKernelGGL(box_filter_kernel<unsigned>, dim3(gate_blocks(outer * n * inner)), dim3(256),
+                       0, (hipStream_t)stream, x, (long long)outer, (long long)n, (long long)inner,
+                       size, out);
+  } else {
+    hipLaunchKernelGGL(box_filter_kernel<unsigned long long>, dim3(gate_blocks(outer * n * inner)),
+                       dim3(256), 0, (hipStream_t)stream, x, (long long)outer, (long long)n,
+                       (long long)inner, size, out);
+  }
   MIA_CHECK_HIP(hipGetLastError());
   return MIA_OK;
 }
