@@ -2,16 +2,20 @@
 // spectrum to n_out/2+1 bins, irfft of length n_out (what scipy.signal.resample does for real
 // input, which is what the reference's resample(res_type="fft") calls).
 //
-// A transform of arbitrary length N is taken as a chirp-z (Bluestein) convolution:
+// Two paths.  Even lengths whose halves factor into 2, 3, 5 and 7 (every whole number of
+// seconds or milliseconds at the usual sample rates) take the direct one: the row is read in
+// place as n_in/2 complex numbers and goes through mixed-radix Stockham passes; the real-input
+// split, the spectrum resize and the packing for the half-length inverse are one kernel.
+// Every other length is transformed as a chirp-z (Bluestein) convolution:
 //   DFT_N(x)[k] = conj(c[k]) * sum_n x[n] conj(c[n]) c[k-n],   c[n] = exp(i pi n^2 / N),
-// the convolution running through power-of-two FFTs of length L >= 2N-1.  Those are
-// register-resident Stockham passes over global memory: one thread owns one radix-R
-// butterfly (R = 16, or 8 / 4 / 2 for the remainder), reads its R inputs L/R apart
-// (consecutive threads read consecutive elements), multiplies by twiddles it derives from
-// one double-precision sincospi, and writes the R outputs of the autosort step; no LDS and
-// no transposes, log16(L) passes over the data.  The inverse transform is the same machine
-// applied to the conjugate spectrum.  Phases are reduced in integers (n^2 mod 2N) before
-// they become angles, so the chirps are exact to float rounding for any length.
+// through power-of-two FFTs of length L >= 2N-1, with the phases reduced in integers
+// (n^2 mod 2N) before they become angles, so the chirps are exact to float rounding.
+//
+// Both use register-resident Stockham passes over global memory: one thread owns one radix-R
+// butterfly, reads its R inputs L/R apart (consecutive threads read consecutive elements),
+// multiplies by twiddles it derives from one double-precision sincospi and a double recurrence,
+// and writes the R outputs of the autosort step; no LDS, no transposes, no twiddle tables.  An
+// inverse transform is the same machine applied to the conjugate spectrum.
 #include "fft_engine.h"
 #include "mia_internal.h"
 
