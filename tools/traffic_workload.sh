@@ -11,6 +11,8 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 cd "$root"
 python3 - "$out" "$w" <<'PY'
+# Per step = everything the library's kernels moved, divided by the number of steps, which is the
+# dispatch count of a kernel launched once per step (the smallest count among the kernels).
 import csv, glob, sys
 from collections import defaultdict
 res = {}
@@ -22,11 +24,10 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
                 k = row["Kernel_Name"].split("(")[0][:60]
                 per_kernel[k][0] += 1
                 per_kernel[k][1] += float(row["Counter_Value"])
-    total = 0.0
+    steps = min(n for n, _ in per_kernel.values())
     for k, (n, v) in sorted(per_kernel.items()):
-        print(f"{sys.argv[2]} {c} {k}: {v / n:.0f} KiB per dispatch ({n} dispatches)")
-        total += v / n
-    res[c] = total
+        print(f"{sys.argv[2]} {c} {k}: {v / n:.0f} KiB per dispatch, {n / steps:g} dispatches per step")
+    res[c] = sum(v for _, v in per_kernel.values()) / steps
 print(f"{sys.argv[2]} per step: fetch {res['FETCH_SIZE']:.0f} KiB (x2 on gfx950), write {res['WRITE_SIZE']:.0f} KiB, "
       f"hbm bytes {int((2 * res['FETCH_SIZE'] + res['WRITE_SIZE']) * 1024)}")
 PY
