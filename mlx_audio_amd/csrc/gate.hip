@@ -119,6 +119,41 @@ __global__ __launch_bounds__(256) void mask_op_kernel(const float* __restrict__ 
   out[g] = op == 0 ? 1.0f - p * (1.0f - a[g]) : a[g] * b[g];
 }
 
+// The last step of the gate in one pass: m = keep ? 1 - p (1 - mask) : mask, then
+// mag * m * exp(i phase), read as (rows, bins, frames) planes and written as the
+// (rows, frames, bins) complex spectrum the inverse STFT kernel reads with coalesced rows;
+// 32 x 32 tiles through LDS.  grid (tiles over frames, tiles over bins, rows), block (32, 8).
+__global__ __launch_bounds__(256) void gate_apply_kernel(const float* __restrict__ mag,
+                                                         const float* __restrict__ mask,
+                                                         const float* __restrict__ phase,
+                                                         long long bins, long long F, int keep,
+                                                         float p, float2* __restrict__ out) {
+  __shared__ float2 tile[32][33];
+  const long long row = blockIdx.z;
+  const long long f0 = (long long)blockIdx.x * 32, k0 = (long long)blockIdx.y * 32;
+  const long long base = row * bins * F;
+  for (int j = threadIdx.y; j < 32; j += 8) {  // j: bin in the tile, x: frame
+    const long long k = k0 + j, f = f0 + threadIdx.x;
+    float2 v = {0.0f, 0.0f};
+    if (k < bins && f < F) {
+      const long long i = base + k * F + f;
+      float m = mask[i];
+      if (keep) m = 1.0f - p * (1.0f - m);
+      const float a = mag[i] * m;
+      float sn, cs;
+      sincosf(phase[i], &sn, &cs);
+      v = {a * cs, a * sn};
+    }
+    tile[j][threadIdx.x] = v;
+  }
+  __syncthreads();
+  float2* __restrict__ dst = out + base;
+  for (int j = threadIdx.y; j < 32; j += 8) {  // j: frame in the tile, x: bin
+    const long long f = f0 + j, k = k0 + threadIdx.x;
+    if (k < bins && f < F) dst[f * bins + k] = tile[threadIdx.x][j];
+  }
+}
+
 static inline unsigned gate_blocks(long long n) { return (unsigned)((n + 255) / 256); }
 
 }  // namespace mia
@@ -199,6 +234,20 @@ int mia_gate_mask(const float* mag, const float* thr, int64_t rows, int bins, in
   hipLaunchKernelGGL(gate_mask_kernel, dim3(gate_blocks(rows * bins * frames)), dim3(256), 0,
                      (hipStream_t)stream, mag, thr, (long long)rows, bins, (long long)frames,
                      per_bin, (long long)rows_thr, gain, mask);
+  MIA_CHECK_HIP(hipGetLastError());
+  return MIA_OK;
+}
+
+int mia_gate_apply(const float* mag, const float* mask, const float* phase, int64_t rows, int64_t bins,
+                   int64_t frames, int keep, float p, void* out, void* stream) {
+  using namespace mia;
+  MIA_REQUIRE(rows >= 0 && bins >= 0 && frames >= 0, "negative shape");
+  if (rows == 0 || bins == 0 || frames == 0) return MIA_OK;
+  MIA_REQUIRE(mag && mask && phase && out, "null pointer");
+  MIA_REQUIRE(rows <= 65535 && (bins + 31) / 32 <= 65535, "at most 65535 rows per call");
+  const dim3 grid((unsigned)((frames + 31) / 32), (unsigned)((bins + 31) / 32), (unsigned)rows);
+  hipLaunchKernelGGL(gate_apply_kernel, grid, dim3(32, 8), 0, (hipStream_t)stream, mag, mask, phase,
+                     (long long)bins, (long long)frames, keep, p, (float2*)out);
   MIA_CHECK_HIP(hipGetLastError());
   return MIA_OK;
 }

@@ -14,7 +14,6 @@ import torch
 
 from .. import _lib
 from .._runtime import as_device_f32, stream_ptr
-from .griffinlim import _polar
 from .stft import istft, magnitude, phase, stft
 
 
@@ -90,6 +89,15 @@ class _Ops:
         self._run("mia_mask_op", mask.data_ptr(), 0, mask.numel(), 0, float(prop_decrease), out.data_ptr())
         return out
 
+    def apply(self, mag, mask, ph, keep, prop_decrease):
+        """mag * mask' * exp(i ph) as a (rows, bins, frames) view of a (rows, frames, bins) buffer,
+        mask' = 1 - prop_decrease (1 - mask) if keep else mask."""
+        rows, bins, frames = mag.shape
+        out = torch.empty((rows, frames, bins), dtype=torch.complex64, device=self.dev)
+        self._run("mia_gate_apply", mag.data_ptr(), mask.data_ptr(), ph.data_ptr(), rows, bins,
+                  frames, int(bool(keep)), float(prop_decrease), out.data_ptr())
+        return out.transpose(1, 2)
+
     def times(self, a, b):
         out = self.new(a.shape)
         self._run("mia_mask_op", a.data_ptr(), b.data_ptr(), a.numel(), 1, 0.0, out.data_ptr())
@@ -145,8 +153,7 @@ def spectral_gate(audio, noise_profile=None, *, sr: int = 22050, n_fft: int = 20
         mask = ops.box(mask, fb, tf)
     if n_grad_freq > 1 or n_grad_time > 1:
         mask = ops.box(mask, n_grad_freq, n_grad_time)
-    mask = ops.keep(mask, prop_decrease)
-    enhanced = _polar(ops.times(mag, mask), ph)
+    enhanced = ops.apply(mag, mask, ph, True, prop_decrease)
     y = istft(enhanced, hop_length=hop_length, win_length=win_length, window=window, center=True,
               length=n_samples)
     return y[0] if is_1d else y
@@ -174,6 +181,6 @@ def spectral_gate_adaptive(audio, *, sr: int = 22050, n_fft: int = 2048, hop_len
     mask = ops.mask(mag, floor, 1.0 + 10 ** (threshold_db / 20.0))
     mask = ops.keep(mask, prop_decrease)
     mask = ops.box(mask, 3, 5)
-    enhanced = _polar(ops.times(mag, mask), ph)
+    enhanced = ops.apply(mag, mask, ph, False, 1.0)
     y = istft(enhanced, hop_length=hop_length, center=True, length=n_samples)
     return y[0] if is_1d else y

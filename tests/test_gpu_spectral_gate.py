@@ -57,6 +57,14 @@ def test_mask_building_blocks(gpu):
     m = ops.mask(d, _dev(full, gpu), 0.5)
     np.testing.assert_allclose(ops.keep(m, 0.8).cpu().numpy(), 1.0 - 0.8 * (1.0 - want), rtol=0, atol=1e-6)
     np.testing.assert_array_equal(ops.times(d, m).cpu().numpy(), mag * m.cpu().numpy())
+    ph = rng.uniform(-np.pi, np.pi, mag.shape).astype(np.float32)
+    mk = m.cpu().numpy()
+    for keep, pd in ((True, 0.8), (False, 1.0)):
+        got = ops.apply(d, m, _dev(ph, gpu), keep, pd)
+        assert got.shape == mag.shape and got.transpose(1, 2).is_contiguous()
+        mm = 1.0 - pd * (1.0 - mk) if keep else mk
+        want = (mag * mm * np.exp(1j * ph.astype(np.float64))).astype(np.complex64)
+        np.testing.assert_allclose(got.cpu().numpy(), want, rtol=0, atol=2e-6)
 
 
 def test_whole_mask_matches_the_oracle(gpu):
