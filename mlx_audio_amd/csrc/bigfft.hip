@@ -462,7 +462,9 @@ int mia_resample_fft(const float* x, int64_t rows, int64_t n_in, int64_t n_out, 
   }
   if (rows == 0) return MIA_OK;
   MIA_REQUIRE(x && tables && out && workspace, "null pointer");
-  if (direct_ok(n_in, n_out) && (((uintptr_t)x | (uintptr_t)out) & 7) == 0) {
+  if (direct_ok(n_in, n_out)) {
+    // the rows are read and written as pairs of samples (both lengths are even)
+    MIA_REQUIRE((((uintptr_t)x | (uintptr_t)out) & 7) == 0, "x and out must be 8-byte aligned");
     const long long Nh = n_in / 2, Mh = n_out / 2, H = Nh > Mh ? Nh : Mh;
     const size_t need_d = 2 * (size_t)rows * (size_t)H * sizeof(float2);
     MIA_REQUIRE(workspace_bytes >= need_d, "workspace too small: %zu bytes, need %zu",
