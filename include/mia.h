@@ -327,11 +327,17 @@ int mia_box_filter(const float* x, int64_t outer, int64_t n, int64_t inner, int 
 int mia_gate_mask(const float* mag, const float* thr, int64_t rows, int bins, int64_t frames,
                   int per_bin, int64_t rows_thr, float gain, float* mask, void* stream);
 int mia_mask_op(const float* a, const float* b, int64_t n, int op, float p, float* out, void* stream);
-/* The closing steps in one pass (spectral_gate.py:215-221): m = keep ? 1 - p (1 - mask) : mask,
- * out = mag * m * exp(i phase); inputs (rows, bins, frames) floats, out complex64 in the
- * (rows, frames, bins) order mia_istft reads fastest. */
+/* mia_gate_mask, optionally mia_mask_op(op 0) and a mia_box_filter over size_freq bins in one
+ * pass, bit-identical to the separate calls (size_freq = 1: no averaging). */
+int mia_gate_mask_box(const float* mag, const float* thr, int64_t rows, int bins, int64_t frames,
+                      int per_bin, int64_t rows_thr, float gain, int keep, float p, int size_freq,
+                      float* out, void* stream);
+/* The closing steps in one pass (spectral_gate.py:207-221): optionally a mia_box_filter of the
+ * mask over size_time frames (1: none), m = keep ? 1 - p (1 - mask) : mask, out = mag * m *
+ * exp(i phase); inputs (rows, bins, frames) floats, out complex64 in the (rows, frames, bins)
+ * order mia_istft reads fastest. */
 int mia_gate_apply(const float* mag, const float* mask, const float* phase, int64_t rows, int64_t bins,
-                   int64_t frames, int keep, float p, void* out, void* stream);
+                   int64_t frames, int keep, float p, int size_time, void* out, void* stream);
 
 /* ---- HTDemucs input normalisation (models/demucs/model.py:206-233) ---------------------
  * mia_normalize_rows: per row of n floats, mean and population standard deviation, then

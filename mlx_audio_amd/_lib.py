@@ -102,7 +102,9 @@ SIGNATURES = {
     "mia_gate_mask": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int64, c_int, c_int64, c_float,
                               c_void_p, c_void_p]),
     "mia_gate_apply": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int,
-                               c_float, c_void_p, c_void_p]),
+                               c_float, c_int, c_void_p, c_void_p]),
+    "mia_gate_mask_box": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int64, c_int, c_int64,
+                                  c_float, c_int, c_float, c_int, c_void_p, c_void_p]),
     "mia_mask_op": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p, c_void_p]),
     "mia_normalize_rows": (c_int, [c_void_p, c_int64, c_int64, c_float, c_void_p, c_void_p, c_void_p,
                                    c_void_p]),

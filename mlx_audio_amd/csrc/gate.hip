@@ -110,6 +110,34 @@ __global__ __launch_bounds__(256) void gate_mask_kernel(const float* __restrict_
   mask[g] = fminf(fmaxf(v, 0.0f), 1.0f);
 }
 
+// The soft mask, optionally the keep step, and a moving average over `size` bins in one pass:
+// out[row, k, f] = mean over kk in [k - size/2, k + (size-1)/2] (clamped) of m(row, kk, f),
+// m = clip((mag - thr * gain) / (mag + eps), 0, 1), then 1 - p (1 - m) if keep.  Every m is the
+// float32 value the separate kernels would have stored, the sum runs in double: bit-identical
+// to gate_mask_kernel (+ mask_op) + box_filter_kernel along the bins.
+__global__ __launch_bounds__(256) void gate_mask_box_kernel(const float* __restrict__ mag,
+                                                            const float* __restrict__ thr,
+                                                            unsigned rows, unsigned bins, unsigned F,
+                                                            int per_bin, unsigned rows_thr, float gain,
+                                                            int keep, float p, int size,
+                                                            float* __restrict__ out) {
+  const unsigned f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= F) return;
+  const unsigned k = blockIdx.y, row = blockIdx.z;
+  const size_t plane = (size_t)row * bins * F;
+  double sum = 0.0;
+  for (int j = (int)k - size / 2; j <= (int)k + (size - 1) / 2; ++j) {
+    const unsigned q = j < 0 ? 0u : (j >= (int)bins ? bins - 1 : (unsigned)j);
+    const size_t i = plane + (size_t)q * F + f;
+    const float t = per_bin ? thr[(rows_thr == 1 ? 0 : (size_t)row * bins) + q] : thr[i];
+    const float m = mag[i];
+    float v = fminf(fmaxf((m - t * gain) / (m + kGateEps), 0.0f), 1.0f);
+    if (keep) v = 1.0f - p * (1.0f - v);
+    sum += (double)v;
+  }
+  out[plane + (size_t)k * F + f] = size == 1 ? (float)sum : (float)(sum / (double)size);
+}
+
 // op 0: out = 1 - p (1 - a);  op 1: out = a * b
 __global__ __launch_bounds__(256) void mask_op_kernel(const float* __restrict__ a,
                                                       const float* __restrict__ b, long long n,
@@ -119,7 +147,8 @@ __global__ __launch_bounds__(256) void mask_op_kernel(const float* __restrict__ 
   out[g] = op == 0 ? 1.0f - p * (1.0f - a[g]) : a[g] * b[g];
 }
 
-// The last step of the gate in one pass: m = keep ? 1 - p (1 - mask) : mask, then
+// The last steps of the gate in one pass: optionally the moving average of the mask over
+// size_time frames, m = keep ? 1 - p (1 - mask) : mask, then
 // mag * m * exp(i phase), read as (rows, bins, frames) planes and written as the
 // (rows, frames, bins) complex spectrum the inverse STFT kernel reads with coalesced rows;
 // 32 x 32 tiles through LDS.  grid (tiles over frames, tiles over bins, rows), block (32, 8).
@@ -127,7 +156,8 @@ __global__ __launch_bounds__(256) void gate_apply_kernel(const float* __restrict
                                                          const float* __restrict__ mask,
                                                          const float* __restrict__ phase,
                                                          long long bins, long long F, int keep,
-                                                         float p, float2* __restrict__ out) {
+                                                         float p, int size_time,
+                                                         float2* __restrict__ out) {
   __shared__ float2 tile[32][33];
   const long long row = blockIdx.z;
   const long long f0 = (long long)blockIdx.x * 32, k0 = (long long)blockIdx.y * 32;
@@ -138,6 +168,14 @@ __global__ __launch_bounds__(256) void gate_apply_kernel(const float* __restrict
     if (k < bins && f < F) {
       const long long i = base + k * F + f;
       float m = mask[i];
+      if (size_time > 1) {  // moving average over the frames first, as box_filter_kernel does it
+        double sum = 0.0;
+        for (long long j = f - size_time / 2; j <= f + (size_time - 1) / 2; ++j) {
+          const long long q = j < 0 ? 0 : (j >= F ? F - 1 : j);
+          sum += (double)mask[base + k * F + q];
+        }
+        m = (float)(sum / (double)size_time);
+      }
       if (keep) m = 1.0f - p * (1.0f - m);
       const float a = mag[i] * m;
       float sn, cs;
@@ -238,16 +276,35 @@ int mia_gate_mask(const float* mag, const float* thr, int64_t rows, int bins, in
   return MIA_OK;
 }
 
-int mia_gate_apply(const float* mag, const float* mask, const float* phase, int64_t rows, int64_t bins,
-                   int64_t frames, int keep, float p, void* out, void* stream) {
+int mia_gate_mask_box(const float* mag, const float* thr, int64_t rows, int bins, int64_t frames,
+                      int per_bin, int64_t rows_thr, float gain, int keep, float p, int size_freq,
+                      float* out, void* stream) {
   using namespace mia;
-  MIA_REQUIRE(rows >= 0 && bins >= 0 && frames >= 0, "negative shape");
+  MIA_REQUIRE(rows >= 0 && bins >= 1 && frames >= 0 && size_freq >= 1,
+              "rows, bins, frames, size_freq must be >= 0, 1, 0, 1");
+  MIA_REQUIRE(rows_thr == rows || (per_bin && rows_thr == 1),
+              "the threshold must have one row per signal row, or a single row of per-bin values");
+  if (rows == 0 || frames == 0) return MIA_OK;
+  MIA_REQUIRE(mag && thr && out, "null pointer");
+  MIA_REQUIRE(rows <= 65535 && bins <= 65535 && frames <= 0x7fffffffLL, "shape too large for one launch");
+  const dim3 grid((unsigned)((frames + 255) / 256), (unsigned)bins, (unsigned)rows);
+  hipLaunchKernelGGL(gate_mask_box_kernel, grid, dim3(256), 0, (hipStream_t)stream, mag, thr,
+                     (unsigned)rows, (unsigned)bins, (unsigned)frames, per_bin, (unsigned)rows_thr,
+                     gain, keep, p, size_freq, out);
+  MIA_CHECK_HIP(hipGetLastError());
+  return MIA_OK;
+}
+
+int mia_gate_apply(const float* mag, const float* mask, const float* phase, int64_t rows, int64_t bins,
+                   int64_t frames, int keep, float p, int size_time, void* out, void* stream) {
+  using namespace mia;
+  MIA_REQUIRE(rows >= 0 && bins >= 0 && frames >= 0 && size_time >= 1, "negative shape or size");
   if (rows == 0 || bins == 0 || frames == 0) return MIA_OK;
   MIA_REQUIRE(mag && mask && phase && out, "null pointer");
   MIA_REQUIRE(rows <= 65535 && (bins + 31) / 32 <= 65535, "at most 65535 rows per call");
   const dim3 grid((unsigned)((frames + 31) / 32), (unsigned)((bins + 31) / 32), (unsigned)rows);
   hipLaunchKernelGGL(gate_apply_kernel, grid, dim3(32, 8), 0, (hipStream_t)stream, mag, mask, phase,
-                     (long long)bins, (long long)frames, keep, p, (float2*)out);
+                     (long long)bins, (long long)frames, keep, p, size_time, (float2*)out);
   MIA_CHECK_HIP(hipGetLastError());
   return MIA_OK;
 }

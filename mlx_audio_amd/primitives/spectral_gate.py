@@ -89,14 +89,36 @@ class _Ops:
         self._run("mia_mask_op", mask.data_ptr(), 0, mask.numel(), 0, float(prop_decrease), out.data_ptr())
         return out
 
-    def apply(self, mag, mask, ph, keep, prop_decrease):
-        """mag * mask' * exp(i ph) as a (rows, bins, frames) view of a (rows, frames, bins) buffer,
-        mask' = 1 - prop_decrease (1 - mask) if keep else mask."""
+    def apply(self, mag, mask, ph, keep, prop_decrease, size_time=1):
+        """mag * mask' * exp(i ph) as a (rows, bins, frames) view of a (rows, frames, bins) buffer;
+        mask' = the mask averaged over size_time frames, then 1 - prop_decrease (1 - .) if keep."""
         rows, bins, frames = mag.shape
         out = torch.empty((rows, frames, bins), dtype=torch.complex64, device=self.dev)
         self._run("mia_gate_apply", mag.data_ptr(), mask.data_ptr(), ph.data_ptr(), rows, bins,
-                  frames, int(bool(keep)), float(prop_decrease), out.data_ptr())
+                  frames, int(bool(keep)), float(prop_decrease), int(size_time), out.data_ptr())
         return out.transpose(1, 2)
+
+    def mask_box(self, mag, thr, gain, keep, prop_decrease, size_freq):
+        """mask(), optionally keep(), and the moving average over size_freq bins in one launch."""
+        rows, bins, frames = mag.shape
+        out = self.new(mag.shape)
+        self._run("mia_gate_mask_box", mag.data_ptr(), thr.data_ptr(), rows, bins, frames,
+                  int(thr.dim() == 2), thr.shape[0], float(gain), int(bool(keep)),
+                  float(prop_decrease), int(size_freq), out.data_ptr())
+        return out
+
+    def gate(self, mag, ph, thr, gain, steps, keep_first, prop_decrease):
+        """The mask pipeline with its first frequency average folded into the mask kernel and
+        its last time average folded into the closing kernel.  steps: [(axis, size), ...] with
+        axis "f" or "t", sizes > 1; keep_first: the keep step comes before the averages (the
+        adaptive variant) instead of after them."""
+        steps = list(steps)
+        first = steps.pop(0)[1] if steps and steps[0][0] == "f" else 1
+        last = steps.pop()[1] if steps and steps[-1][0] == "t" else 1
+        mask = self.mask_box(mag, thr, gain, keep_first, prop_decrease, first)
+        for axis, size in steps:
+            mask = self.box(mask, size, 1) if axis == "f" else self.box(mask, 1, size)
+        return self.apply(mag, mask, ph, not keep_first, prop_decrease, last)
 
     def times(self, a, b):
         out = self.new(a.shape)
@@ -146,14 +168,15 @@ def spectral_gate(audio, noise_profile=None, *, sr: int = 22050, n_fft: int = 20
     gain = 10 ** (threshold_db / 20.0)
     if noise_profile is None and not stationary:
         gain *= (1 + n_std_thresh)
-    mask = ops.mask(mag, thr, gain)
+    steps = []
     if freq_smooth_hz > 0 or time_smooth_ms > 0:
         fb = max(1, int(freq_smooth_hz * n_fft / sr))
         tf = max(1, int(time_smooth_ms * sr / (1000 * hop_length)))
-        mask = ops.box(mask, fb, tf)
+        steps += [("f", fb), ("t", tf)]
     if n_grad_freq > 1 or n_grad_time > 1:
-        mask = ops.box(mask, n_grad_freq, n_grad_time)
-    enhanced = ops.apply(mag, mask, ph, True, prop_decrease)
+        steps += [("f", int(n_grad_freq)), ("t", int(n_grad_time))]
+    steps = [(a, n) for a, n in steps if n > 1]
+    enhanced = ops.gate(mag, ph, thr, gain, steps, False, prop_decrease)
     y = istft(enhanced, hop_length=hop_length, win_length=win_length, window=window, center=True,
               length=n_samples)
     return y[0] if is_1d else y
@@ -178,9 +201,7 @@ def spectral_gate_adaptive(audio, *, sr: int = 22050, n_fft: int = 2048, hop_len
     mag, ph = magnitude(C), phase(C)
     ops = _Ops(mag.device)
     floor = ops.time_min(mag, ahead + back + 1)
-    mask = ops.mask(mag, floor, 1.0 + 10 ** (threshold_db / 20.0))
-    mask = ops.keep(mask, prop_decrease)
-    mask = ops.box(mask, 3, 5)
-    enhanced = ops.apply(mag, mask, ph, False, 1.0)
+    enhanced = ops.gate(mag, ph, floor, 1.0 + 10 ** (threshold_db / 20.0), [("f", 3), ("t", 5)],
+                        True, prop_decrease)
     y = istft(enhanced, hop_length=hop_length, center=True, length=n_samples)
     return y[0] if is_1d else y

@@ -59,6 +59,18 @@ def test_mask_building_blocks(gpu):
     np.testing.assert_array_equal(ops.times(d, m).cpu().numpy(), mag * m.cpu().numpy())
     ph = rng.uniform(-np.pi, np.pi, mag.shape).astype(np.float32)
     mk = m.cpu().numpy()
+    # the fused forms are bit-identical to the separate launches
+    for keep, pd, size in ((False, 1.0, 1), (True, 0.7, 1), (False, 1.0, 9), (True, 0.7, 3), (False, 1.0, 200)):
+        sep = ops.mask(d, _dev(thr, gpu), 0.1)
+        if keep:
+            sep = ops.keep(sep, pd)
+        sep = ops.box(sep, size, 1)
+        assert torch.equal(ops.mask_box(d, _dev(thr, gpu), 0.1, keep, pd, size), sep)
+    assert torch.equal(ops.mask_box(d, _dev(full, gpu), 0.5, False, 1.0, 4), ops.box(ops.mask(d, _dev(full, gpu), 0.5), 4, 1))
+    assert torch.equal(ops.mask_box(d, _dev(thr[:1], gpu), 0.1, False, 1.0, 2), ops.box(ops.mask(d, _dev(thr[:1], gpu), 0.1), 2, 1))
+    php = _dev(rng.uniform(-np.pi, np.pi, mag.shape).astype(np.float32), gpu)
+    for size in (2, 4, 5, 150):
+        assert torch.equal(ops.apply(d, m, php, True, 0.9, size), ops.apply(d, ops.box(m, 1, size), php, True, 0.9))
     for keep, pd in ((True, 0.8), (False, 1.0)):
         got = ops.apply(d, m, _dev(ph, gpu), keep, pd)
         assert got.shape == mag.shape and got.transpose(1, 2).is_contiguous()
