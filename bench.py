@@ -117,6 +117,14 @@ def make_workload(name: str, clips: int, device, seed: int):
                 f"spectral centroid + bandwidth + roll-off + flatness of {clips} spectrograms "
                 "(1025 bins x 938 frames = 30 s @16 kHz, n_fft 2048 hop 512)",
                 "spectral features audio-hours/sec (4 statistics)")
+    if name == "features_all":
+        from mlx_audio_amd.primitives import spectrogram_statistics
+
+        S = torch.rand((clips, 1025, 938), generator=gen, device=device, dtype=torch.float32) + 0.05
+        abytes = clips * (1025 * 938 * 4 + 4 * 938 * 4)   # the spectrogram once, four rows out
+        return (lambda: spectrogram_statistics(S, sr=16000, power=2.0), clips * 30.0 / 3600.0, abytes,
+                f"centroid + bandwidth + roll-off + flatness of {clips} spectrograms (1025 x 938) in "
+                "one launch", "spectral features (one launch) audio-hours/sec")
     if name == "contrast":
         from mlx_audio_amd.primitives import spectral_contrast
 
@@ -195,6 +203,7 @@ KERNEL_OF = {
     "griffinlim": "per iteration istft_kernel<2048> + fwd_kernel<2048> + griffinlim_update_kernel",
     "onset": "onset_flux_shift_kernel (a wave per 64 frames, lagged values by lane shift)",
     "features_y": "fwd_kernel<2048> with the statistics epilogue (no spectrogram in memory)",
+    "features_all": "spectral_stat_kernel, all four statistics in two passes over the bins",
     "features": "spectral_stat_kernel x 4 (one thread per frame, bins walked in order)",
     "resample_fft": "stockham_pass_kernel<16> x 22 + chirp / spectrum kernels (two chirp-z "
                     "convolutions per clip)",
@@ -293,7 +302,7 @@ def main() -> None:
               "torch.distributed.run for N>1", file=sys.stderr)
 
     default_clips = {"whisper128": 1024, "clap64": 1024, "mfcc40": 1024, "htdemucs": 32,
-                     "resample": 512, "resample_fft": 64, "features": 512, "contrast": 512, "onset": 4096, "griffinlim": 64, "spectral_gate": 64, "demucs_front": 16, "features_y": 512}
+                     "resample": 512, "resample_fft": 64, "features": 512, "contrast": 512, "onset": 4096, "griffinlim": 64, "spectral_gate": 64, "demucs_front": 16, "features_y": 512, "features_all": 512}
     clips = args.clips or default_clips.get(args.workload, 1024)
     step, units, abytes, desc, metric = make_workload(args.workload, clips, device, 1234 + rank)
 

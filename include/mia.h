@@ -249,6 +249,7 @@ int mia_resample_fft(const float* x, int64_t rows, int64_t n_in, int64_t n_out, 
 #define MIA_STAT_BANDWIDTH 1
 #define MIA_STAT_ROLLOFF 2
 #define MIA_STAT_FLATNESS 3
+#define MIA_STAT_ALL 4 /* the four at once, two reads of S: out (rows, 4, frames) in the order above */
 int mia_spectral_stat(const float* S, int64_t rows, int bins, int64_t frames, const float* freq,
                       const float* aux, int mode, float p, int norm, float fraction, float amin,
                       float power, float* out, void* stream);

@@ -70,6 +70,45 @@ __global__ __launch_bounds__(256) void spectral_stat_kernel(
       }
     }
     result = freq[hit];
+  } else if (mode == 4) {
+    // all four in two passes: sums first, then the spread around the centroid and the
+    // roll-off point; out is (rows, 4, frames) = centroid, bandwidth, roll-off, flatness, each
+    // value what the single-statistic modes compute
+    float ws = 0.0f, ts = 0.0f, ls = 0.0f, as = 0.0f;
+#pragma unroll 8
+    for (int k = 0; k < bins; ++k) {
+      const float v = col[(long long)k * F];
+      ws += freq[k] * v;
+      ts += v;
+      float u = pow_in(v, power_mode, power);
+      u = u < amin ? amin : u;
+      ls += logf(u);
+      as += u;
+    }
+    const float c = ws / (ts + kDivEps);
+    const float thr = fraction * ts;
+    float bw = 0.0f, cs = 0.0f;
+    int hit = bins - 1;
+    bool open = true;
+#pragma unroll 8
+    for (int k = 0; k < bins; ++k) {
+      const float v = col[(long long)k * F];
+      const float d = fabsf(freq[k] - c);
+      bw += v * (p == 2.0f ? d * d : (p == 1.0f ? d : powf(d, p)));
+      cs += v;
+      if (open && cs >= thr) {
+        hit = k;
+        open = false;
+      }
+    }
+    if (norm) bw = bw / (ts + kDivEps);
+    bw = p == 2.0f ? sqrtf(bw) : (p == 1.0f ? bw : powf(bw, 1.0f / p));
+    float* __restrict__ o = out + row * 4 * F + f;
+    o[0] = c;
+    o[F] = bw;
+    o[2 * F] = freq[hit];
+    o[3 * F] = expf(ls / (float)bins) / (as / (float)bins + kDivEps);
+    return;
   } else {
     float ls = 0.0f, as = 0.0f;
 #pragma unroll 8
@@ -185,10 +224,11 @@ int mia_spectral_stat(const float* S, int64_t rows, int bins, int64_t frames, co
                       float power, float* out, void* stream) {
   using namespace mia;
   MIA_REQUIRE(rows >= 0 && bins >= 1 && frames >= 0, "rows, bins, frames must be >= 0, 1, 0");
-  MIA_REQUIRE(mode >= MIA_STAT_CENTROID && mode <= MIA_STAT_FLATNESS, "unknown statistic %d", mode);
+  MIA_REQUIRE(mode >= MIA_STAT_CENTROID && mode <= MIA_STAT_ALL, "unknown statistic %d", mode);
   if (rows == 0 || frames == 0) return MIA_OK;
   MIA_REQUIRE(S && out, "null pointer");
   MIA_REQUIRE(mode == MIA_STAT_FLATNESS || freq, "this statistic needs the bin frequencies");
+  MIA_REQUIRE(mode != MIA_STAT_ALL || p > 0.0f, "p must be > 0");
   MIA_REQUIRE(mode != MIA_STAT_BANDWIDTH || (aux && p > 0.0f),
               "the bandwidth needs the centroid of every frame and p > 0");
   const long long total = (long long)rows * frames;

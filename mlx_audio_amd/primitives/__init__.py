@@ -3,7 +3,7 @@
 
 from .._lib import HAS_HIP_EXT, has_hip_extensions
 from .convert import amplitude_to_db, db_to_amplitude, db_to_power, power_to_db
-from .features import (fused_statistics, spectral_bandwidth, spectral_centroid, spectral_contrast,
+from .features import (fused_statistics, spectrogram_statistics, spectral_bandwidth, spectral_centroid, spectral_contrast,
                        spectral_flatness, spectral_rolloff, zero_crossing_rate)
 from .griffinlim import griffinlim, griffinlim_iter
 from .mel import hz_to_mel, mel_filterbank, mel_to_hz, melspectrogram
@@ -22,7 +22,7 @@ __all__ = [
     "power_to_db", "amplitude_to_db", "db_to_power", "db_to_amplitude",
     "resample", "resample_poly",
     "spectral_centroid", "spectral_bandwidth", "spectral_rolloff", "spectral_flatness",
-    "spectral_contrast", "zero_crossing_rate", "fused_statistics",
+    "spectral_contrast", "zero_crossing_rate", "fused_statistics", "spectrogram_statistics",
     "onset_strength", "onset_detect", "onset_strength_multi",
     "griffinlim", "griffinlim_iter",
     "spectral_gate", "spectral_gate_adaptive",

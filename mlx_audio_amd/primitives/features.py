@@ -82,6 +82,30 @@ def fused_statistics(y, sr: int = 22050, n_fft: int = 2048, hop_length: int = 51
     return out[0] if is_1d else out
 
 
+def spectrogram_statistics(S, sr: int = 22050, n_fft: int = 2048, freq=None, p: float = 2.0,
+                           norm: bool = True, roll_percent: float = 0.85, amin: float = 1e-10,
+                           power: float = 1.0) -> torch.Tensor:
+    """Centroid, bandwidth, roll-off and flatness of a magnitude spectrogram in one launch that
+    reads it twice (the four separate functions read it five times).  Returns (4, frames) or
+    (batch, 4, frames); `power` is applied to S for the flatness only (2.0 reproduces
+    spectral_flatness's default on magnitudes).  No counterpart function in the reference."""
+    if roll_percent < 0.0 or roll_percent > 1.0:
+        raise ValueError(f"roll_percent must be within [0, 1], got {roll_percent}")
+    S = _compute_spectrogram(None, S, n_fft, 512, None, "hann", True, "constant")
+    batched = S.dim() == 3
+    Sb = (S if batched else S[None]).contiguous()
+    rows, bins, frames = Sb.shape
+    fdev = _default_freq_dev(sr, n_fft, Sb.device) if freq is None else _dev_vector(freq, Sb.device)
+    if fdev.numel() != bins:
+        raise ValueError(f"freq has {fdev.numel()} entries but the spectrogram has {bins} bins")
+    out = torch.empty((rows, 4, frames), dtype=torch.float32, device=Sb.device)
+    with torch.cuda.device(Sb.device):
+        _lib.check(_lib.lib().mia_spectral_stat(
+            Sb.data_ptr(), rows, bins, frames, fdev.data_ptr(), 0, 4, float(p), int(bool(norm)),
+            float(roll_percent), float(amin), float(power), out.data_ptr(), stream_ptr(Sb.device)))
+    return out if batched else out[0]
+
+
 def _fused_ok(y, S, freq, n_fft) -> bool:
     return (S is None and y is not None and freq is None
             and bool(_lib.lib().mia_fft_size_supported(int(n_fft))))

@@ -165,6 +165,22 @@ def test_fused_statistics_equal_the_spectrogram_path(gpu, n_fft, hop):
     torch.testing.assert_close(one, fused_statistics(yd, hop_length=hop, **kw)[0], rtol=0, atol=0)
 
 
+def test_all_four_in_one_launch_equal_the_single_statistics(gpu):
+    from mlx_audio_amd.primitives import spectrogram_statistics
+
+    rng = np.random.default_rng(21)
+    for shape in ((3, 1025, 60), (513, 33), (2, 129, 300)):
+        S = _dev(_spec(rng, shape), gpu)
+        n_fft = 2 * (shape[-2] - 1)
+        for p_exp, norm, roll in ((2.0, True, 0.85), (1.0, False, 0.3), (3.0, True, 1.0)):
+            allf = spectrogram_statistics(S, sr=22050, n_fft=n_fft, p=p_exp, norm=norm, roll_percent=roll, power=2.0)
+            kw = dict(S=S, sr=22050, n_fft=n_fft)
+            assert torch.equal(allf[..., 0:1, :], spectral_centroid(**kw))
+            assert torch.equal(allf[..., 1:2, :], spectral_bandwidth(p=p_exp, norm=norm, **kw))
+            assert torch.equal(allf[..., 2:3, :], spectral_rolloff(roll_percent=roll, **kw))
+            assert torch.equal(allf[..., 3:4, :], spectral_flatness(S=S * S))
+
+
 def test_short_signals_and_c_abi_checks(gpu):
     with pytest.raises(ValueError, match="must be >= frame_length"):
         zero_crossing_rate(_dev(np.zeros(10, np.float32), gpu), frame_length=64, center=False)
