@@ -14,7 +14,10 @@ import torch
 
 from .. import _lib
 from .._runtime import require_gpu, stream_ptr
-from .stft import istft, magnitude, phase, stft
+from .stft import _istft_raw, _stft_raw, istft, magnitude, phase, stft
+
+
+_FEED_UNTRIMMED = True   # the loop's shortcut described in griffinlim(); tests switch it off
 
 
 def _dev_f32(x) -> torch.Tensor:
@@ -91,10 +94,23 @@ def griffinlim(S, n_iter: int = 32, hop_length=None, win_length=None, n_fft=None
     tprev = rebuilt.clone()
     kw = dict(hop_length=hop_length, win_length=win_length, n_fft=n_fft, window=window,
               center=center)
+    # With centre padding by zeros the trimmed signal, padded again, is the untrimmed
+    # overlap-add output with its first and last n_fft/2 samples zeroed: the forward transform
+    # can read that buffer as it stands (no trimming view, no copy to make it contiguous) and
+    # produces bit for bit what istft() followed by stft() does.
+    in_place = _FEED_UNTRIMMED and center and pad_mode == "constant" and n_fft % 2 == 0
     for _ in range(n_iter):
-        y = istft(rebuilt.transpose(1, 2), length=length, **kw)
-        c_new = stft(y, pad_mode=pad_mode, **kw)            # (rows, bins, frames') view
-        c_new = _fit_frames(c_new.transpose(1, 2), frames)  # physical order, exact frame count
+        if in_place:
+            padded = (length + n_fft) if length is not None else n_fft + (frames - 1) * hop_length
+            y_full = _istft_raw(rebuilt.transpose(1, 2), n_fft, hop_length, win_length, window, padded)
+            y_full[:, :n_fft // 2].zero_()
+            y_full[:, padded - n_fft // 2:].zero_()
+            c_new = _stft_raw(y_full, n_fft, hop_length, win_length, window, False, "constant")
+            c_new = _fit_frames(c_new, frames)
+        else:
+            y = istft(rebuilt.transpose(1, 2), length=length, **kw)
+            c_new = stft(y, pad_mode=pad_mode, **kw)            # (rows, bins, frames') view
+            c_new = _fit_frames(c_new.transpose(1, 2), frames)  # physical order, exact frame count
         _update(c_new, mag_t, tprev, rebuilt, momentum)
     y = istft(rebuilt.transpose(1, 2), length=length, **kw)
     return y if batched else y[0]

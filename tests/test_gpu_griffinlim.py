@@ -61,6 +61,24 @@ def test_short_runs_track_the_oracle(gpu, kw):
     assert one.dim() == 1
 
 
+def test_in_place_iteration_equals_the_trimmed_form(gpu, monkeypatch):
+    """Feeding the forward transform from the untrimmed overlap-add buffer gives bit for bit
+    what istft() followed by stft() gives."""
+    import importlib
+
+    mod = importlib.import_module("mlx_audio_amd.primitives.griffinlim")
+    y, S = _target()
+    cases = [({}, S), ({"length": 8000}, S), ({"momentum": 0.0, "init": "zeros"}, S)]
+    kw = {"hop_length": 64, "win_length": 400, "window": "hamming"}
+    cases.append((kw, np.abs(sp.stft(y, n_fft=512, **kw)).astype(np.float32)))
+    for kw, Sk in cases:
+        fast = griffinlim(_dev(Sk, gpu), n_iter=3, random_state=1, **kw)
+        monkeypatch.setattr(mod, "_FEED_UNTRIMMED", False)
+        slow = griffinlim(_dev(Sk, gpu), n_iter=3, random_state=1, **kw)
+        monkeypatch.setattr(mod, "_FEED_UNTRIMMED", True)
+        assert torch.equal(fast, slow), kw
+
+
 def test_long_run_converges_like_the_oracle(gpu):
     y, S = _target(n=16384, n_fft=1024, hop=256)
     got = griffinlim(_dev(S, gpu), n_iter=32, random_state=0).cpu().numpy()
