@@ -154,6 +154,18 @@ int mia_melspectrogram(const mia_plan* plan, const float* y, int64_t B, int64_t 
                        int per_clip, float* out, void* workspace,
                        size_t workspace_bytes, void* stream);
 
+/* mia_melspectrogram for callers that cannot allocate device memory (code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc): the same kernels and the
+ * same result bit for bit, but the clamp keys live in a device array of the library itself
+ * (512 KiB per GPU, held until the process ends) instead of a caller workspace.  It has no
+ * counterpart in the reference.  At most MIA_STATIC_MAX_CLIPS clips per call (more: use
+ * mia_melspectrogram); calls that overlap in time on one GPU share the array and race — issue
+ * them on one stream or order them yourself.  Calls no hipMalloc / hipFree. */
+#define MIA_STATIC_MAX_CLIPS 65535
+int mia_melspectrogram_static(const mia_plan* plan, const float* y, int64_t B, int64_t T,
+                              int epilogue, float ref, float amin, float coef, float top_db,
+                              int per_clip, float* out, void* stream);
+
 /* MFCC from waveform: the chain above with MIA_EPI_DB(ref=1, amin=1e-10,
  * top_db=80) followed by DCT-II along the mel axis and the lifter
  * (primitives/mfcc.py:226-281).  out: (B, n_mfcc, F). */

@@ -176,6 +176,38 @@ int mia_fft_size_supported(int n_fft) { return fft_size_supported(n_fft) ? 1 : 0
 
 }  // extern "C"
 
+// Clamp keys of mia_melspectrogram_static: the two key arrays (per-clip maximum and
+// minimum, MIA_STATIC_MAX_CLIPS + 1 entries each) that mia_melspectrogram takes from
+// its workspace argument.  Every GPU the library runs on holds its own copy of this
+// array at its own address until the process ends.  In host code the name is only a
+// handle for hipGetSymbolAddress: kernels and memsets get the device address that
+// scratch_resolve() stored for the device, never the name.
+static constexpr size_t kStaticKeyBytes =
+    (sizeof(int) * ((size_t)MIA_STATIC_MAX_CLIPS + 1) + 255) & ~(size_t)255;
+static __device__ __align__(256) unsigned char scratch[2 * kStaticKeyBytes];
+
+static constexpr int kMaxDevices = 64;
+static std::mutex g_scratch_mutex;
+static void* g_scratch_ptr[kMaxDevices] = {};
+
+// Device address of `scratch` on `device`, which must be the current device; looked up
+// once per device (mia_plan_create does it, so every plan's device is covered).
+static int scratch_resolve(int device, void** out) {
+  MIA_REQUIRE(device >= 0 && device < kMaxDevices, "device index %d out of range", device);
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  if (g_scratch_ptr[device] == nullptr) {
+    int cur = -1;
+    MIA_CHECK_HIP(hipGetDevice(&cur));
+    MIA_REQUIRE(cur == device, "device %d is not current (current: %d)", device, cur);
+    void* ptr = nullptr;
+    MIA_CHECK_HIP(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+    MIA_REQUIRE(ptr != nullptr, "hipGetSymbolAddress returned a null address");
+    g_scratch_ptr[device] = ptr;
+  }
+  *out = g_scratch_ptr[device];
+  return MIA_OK;
+}
+
 static void plan_free(mia_plan* p) {
   if (!p) return;
   (void)hipFree(p->d_window);
@@ -387,6 +419,10 @@ int mia_plan_create(const mia_plan_desc* d, mia_plan** out) {
   if (hipGetDevice(&p->device) != hipSuccess) {
     set_error("hipGetDevice failed (no GPU?)");
     return fail(MIA_ERR_HIP);
+  }
+  {
+    void* keys = nullptr;  // the static clamp keys of this device (mia_melspectrogram_static)
+    if ((rc = scratch_resolve(p->device, &keys)) != MIA_OK) return fail(rc);
   }
   p->n_fft = d->n_fft;
   p->hop = d->hop_length;
@@ -671,6 +707,21 @@ int mia_melspectrogram(const mia_plan* plan, const float* y, int64_t B, int64_t 
                        void* workspace, size_t workspace_bytes, void* stream) {
   return mel_forward(plan, y, B, T, epilogue, ref, amin, coef, top_db, per_clip, out, workspace,
                      workspace_bytes, (hipStream_t)stream);
+}
+
+int mia_melspectrogram_static(const mia_plan* plan, const float* y, int64_t B, int64_t T,
+                              int epilogue, float ref, float amin, float coef, float top_db,
+                              int per_clip, float* out, void* stream) {
+  MIA_REQUIRE(plan != nullptr, "null plan");
+  MIA_REQUIRE(B <= MIA_STATIC_MAX_CLIPS,
+              "mia_melspectrogram_static holds clamp keys for at most %d clips, got %lld "
+              "(use mia_melspectrogram with a workspace)", MIA_STATIC_MAX_CLIPS, (long long)B);
+  void* keys = nullptr;
+  int rc = scratch_resolve(plan->device, &keys);  // a table lookup after mia_plan_create
+  if (rc != MIA_OK) return rc;
+  static_assert(2 * kStaticKeyBytes == sizeof(scratch), "both key arrays fit");
+  return mel_forward(plan, y, B, T, epilogue, ref, amin, coef, top_db, per_clip, out, keys,
+                     2 * kStaticKeyBytes, (hipStream_t)stream);
 }
 
 int mia_spectral_stats(const mia_plan* plan, const float* y, int64_t B, int64_t T, const float* freq,
