@@ -92,6 +92,15 @@ typedef struct mia_plan_desc {
  * csrc/primitives/dct.cpp:19-42). */
 int mia_plan_create(const mia_plan_desc* desc, mia_plan** out);
 int mia_plan_destroy(mia_plan* plan);
+/* Ablation and test knobs of a plan, and facts about it; neither has a counterpart in the
+ * reference.  Options: "w400_table_sweep" (1: the n_fft = 400 kernel walks its filterbank
+ * from tables even when the bank is one of the two compiled-in Whisper banks; results are
+ * bit-identical either way), "w400_vgpr_staging" (1: that kernel stages its samples through
+ * registers instead of LDS-DMA loads; bit-identical too).  Info keys: "w400_bank" (80 / 128 when the compiled sweep
+ * applies, else 0), "w400_tables" (1 when the n_fft = 400 kernel serves the plan),
+ * "compute_units".  Not thread-safe against launches that use the plan. */
+int mia_plan_set_option(mia_plan* plan, const char* key, int value);
+int mia_plan_get_info(const mia_plan* plan, const char* key);
 /* 1 + (T + 2*pad - n_fft) / hop, or a negative error if the signal is too short
  * (primitives/_frame_impl.py:116-122). */
 int64_t mia_plan_num_frames(const mia_plan* plan, int64_t T);

@@ -57,6 +57,8 @@ SIGNATURES = {
     "mia_dct_matrix": (c_int, [c_int, c_int, c_int, POINTER(c_float)]),
     "mia_plan_create": (c_int, [POINTER(PlanDesc), POINTER(c_void_p)]),
     "mia_plan_destroy": (c_int, [c_void_p]),
+    "mia_plan_set_option": (c_int, [c_void_p, c_char_p, c_int]),
+    "mia_plan_get_info": (c_int, [c_void_p, c_char_p]),
     "mia_plan_num_frames": (c_int64, [c_void_p, c_int64]),
     "mia_fft_size_supported": (c_int, [c_int]),
     "mia_stft": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_float, c_void_p, c_void_p]),

@@ -420,6 +420,10 @@ int mia_plan_create(const mia_plan_desc* d, mia_plan** out) {
     set_error("hipGetDevice failed (no GPU?)");
     return fail(MIA_ERR_HIP);
   }
+  if (hipDeviceGetAttribute(&p->cus, hipDeviceAttributeMultiprocessorCount, p->device) !=
+          hipSuccess || p->cus <= 0) {
+    p->cus = 256;
+  }
   {
     void* keys = nullptr;  // the static clamp keys of this device (mia_melspectrogram_static)
     if ((rc = scratch_resolve(p->device, &keys)) != MIA_OK) return fail(rc);
@@ -472,6 +476,7 @@ int mia_plan_create(const mia_plan_desc* d, mia_plan** out) {
     if (N == 400 && d->hop_length == 160 && d->power == 2.0f) {
       rc = build_w400_tables(p, d->window, d->mel_basis, d->n_mels, bins);
       if (rc != MIA_OK) return fail(rc);
+      if (p->d_sweep_meta != nullptr) p->w400_bank = w400_compiled_bank(d->mel_basis, d->n_mels, bins);
     }
   }
   if (d->n_mfcc > 0) {
@@ -491,6 +496,29 @@ int mia_plan_create(const mia_plan_desc* d, mia_plan** out) {
   }
   *out = p;
   return MIA_OK;
+}
+
+int mia_plan_set_option(mia_plan* plan, const char* key, int value) {
+  MIA_REQUIRE(plan != nullptr && key != nullptr, "null argument");
+  if (strcmp(key, "w400_table_sweep") == 0) {
+    plan->opt_table_sweep = value != 0;
+    return MIA_OK;
+  }
+  if (strcmp(key, "w400_vgpr_staging") == 0) {
+    plan->opt_vgpr_staging = value != 0;
+    return MIA_OK;
+  }
+  set_error("unknown plan option '%s'", key);
+  return MIA_ERR_INVALID;
+}
+
+int mia_plan_get_info(const mia_plan* plan, const char* key) {
+  if (plan == nullptr || key == nullptr) return MIA_ERR_INVALID;
+  if (strcmp(key, "w400_bank") == 0) return plan->w400_bank;
+  if (strcmp(key, "w400_tables") == 0) return plan->d_sweep_meta != nullptr;
+  if (strcmp(key, "compute_units") == 0) return plan->cus;
+  set_error("unknown plan info '%s'", key);
+  return MIA_ERR_INVALID;
 }
 
 int mia_plan_destroy(mia_plan* plan) {
@@ -643,7 +671,8 @@ extern "C" size_t mia_mel_workspace_bytes(const mia_plan* plan, int64_t B, int64
 // kernel's 32-bit offsets), else the generic one.
 static int forward_mel_dispatch(const mia_plan* plan, const FwdParams& p, hipStream_t s) {
   if (plan->d_sweep_meta != nullptr && p.n_mels * p.F < (1LL << 30)) {
-    W400Tables tb{plan->d_win16, plan->d_tw16, plan->d_sweep_meta, plan->d_sweep_w};
+    W400Tables tb{plan->d_win16, plan->d_tw16, plan->d_sweep_meta, plan->d_sweep_w,
+                  plan->w400_bank, plan->opt_table_sweep, plan->opt_vgpr_staging, plan->cus};
     return launch_logmel400(p, tb, s);
   }
   return launch_forward(plan, p, 1, s);
@@ -692,6 +721,9 @@ static int mel_forward(const mia_plan* plan, const float* y, int64_t B, int64_t 
 #endif
   rc = forward_mel_dispatch(plan, p, s);
   if (rc != MIA_OK) return rc;
+#ifdef MIA_DEBUG_HOOKS
+  if (p.dbg != 0) return rc;  // ablation runs time the main kernel alone (their data is garbage)
+#endif
   if (clamp && B > 0) {
     const float top = epilogue == MIA_EPI_WHISPER ? 8.0f : top_db;
     rc = launch_floor_clips(out, B, (long long)plan->n_mels * p.F, max_keys, min_keys, epilogue,

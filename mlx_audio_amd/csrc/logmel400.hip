@@ -36,6 +36,14 @@
 // i - 1) is all the workgroup needs.
 #include "fft_engine.h"
 #include "mia_internal.h"
+// the steps of the generated sweep programs, on a context object c (SweepCtx below)
+#define SW_LD(k) x = c.ld(k);
+#define SW_MUL(a, w) a = (w) * x;
+#define SW_FMA(a, w) a = fmaf((w), x, a);
+#define SW_EMIT(j, a) c.emit(std::integral_constant<int, (j)>{}, a);
+#define SW_EMIT0(j) c.emit(std::integral_constant<int, (j)>{}, 0.0f);
+#define SW_END(n) c.end_of_sweep(std::integral_constant<int, (n)>{});
+#include "w400_sweep_gen.inc"
 
 namespace mia {
 
@@ -62,8 +70,9 @@ static_assert(LDS_DWORDS * 4 <= 160 * 1024, "LDS budget");
 }  // namespace w400
 
 // Profiling hooks, compiled in only with -DMIA_DEBUG_HOOKS (tools/abl.sh, tools/stamps.py):
-// FwdParams::dbg bit 1 skips the mel sweep, bit 4 the output stores, bit 8 enables the
-// per-phase cycle stamps of workgroup 77 (needs -DMIA_W400_STAMPS as well).
+// FwdParams::dbg bit 1 skips the mel sweep, bit 2 the FFT arithmetic (LDS traffic kept),
+// bit 4 the output stores, bit 16 the global loads, bit 8 enables the per-phase cycle
+// stamps of workgroup 77 (needs -DMIA_W400_STAMPS as well).
 #ifdef MIA_DEBUG_HOOKS
 #define MIA_DBG(p, bit) ((p).dbg & (bit))
 __device__ unsigned long long* g_dbgbuf = nullptr;
@@ -71,11 +80,23 @@ __device__ unsigned long long* g_dbgbuf = nullptr;
 #define MIA_DBG(p, bit) 0
 #endif
 #if defined(MIA_DEBUG_HOOKS) && defined(MIA_W400_STAMPS)
-#define STAMP(i)                                                                          \
-  if ((p.dbg & 8) && g_dbgbuf && blockIdx.x == 77 && (threadIdx.x & 63) == 0 && it < 4)    \
-    g_dbgbuf[(it * 16 + (threadIdx.x >> 6)) * 16 + (i)] = __builtin_readcyclecounter();
+#ifndef MIA_W400_STAMP_IT0
+#define MIA_W400_STAMP_IT0 0  // first of the four stamped tiles of the workgroup's run
+#endif
+// Stamps are taken into registers by every wave (one s_memtime each) and written out once
+// per tile by workgroup 77 only, so that the stamped kernel runs like the real one.
+#define STAMP_DECL unsigned long long stamp_[8];
+#define STAMP(i) stamp_[i] = __builtin_readcyclecounter();
+#define STAMP_FLUSH                                                                        \
+  if ((p.dbg & 8) && blockIdx.x == 77 && (threadIdx.x & 63) == 0 &&                        \
+      it >= MIA_W400_STAMP_IT0 && it < MIA_W400_STAMP_IT0 + 4 && g_dbgbuf) {               \
+    for (int i_ = 0; i_ < 8; ++i_)                                                         \
+      g_dbgbuf[((it - MIA_W400_STAMP_IT0) * 16 + (threadIdx.x >> 6)) * 16 + i_] = stamp_[i_]; \
+  }
 #else
+#define STAMP_DECL
 #define STAMP(i)
+#define STAMP_FLUSH
 #endif
 
 // The floor max(x, lo) of the log epilogue, written so that a NaN stays a NaN (as in the
@@ -163,6 +184,46 @@ __device__ __forceinline__ void mel_sweep(const FwdParams& p, const float* __res
   }
 }
 
+// The same sweep for a filterbank known at build time (w400_sweep_gen.inc): the per-wave
+// program is straight-line code with literal weights, so there is no per-bin control word,
+// no weight load and no loop.  Arithmetic and its order equal mel_sweep's (first
+// contribution a product, the rest fused multiply-adds over ascending bins), so the two
+// paths give the same bits.
+template <int EPI>
+struct SweepCtx {
+  const FwdParams& p;
+  const float* __restrict__ pr;  // this lane's column of the power tile
+  char* __restrict__ rowp;       // wave-uniform: first output row of the wave, first frame of the tile
+  unsigned voff, f4;             // byte offset of this lane's next store; one row
+  unsigned mhi, mlo;             // bit patterns of the largest / smallest floored power
+  __device__ __forceinline__ float ld(int k) const { return pr[4 * k]; }
+  template <int J>
+  __device__ __forceinline__ void emit(std::integral_constant<int, J>, float acc) {
+    float outv = acc;
+    if (EPI != MIA_EPI_NONE) {
+      const float m = floor_keep_nan(acc, EPI == MIA_EPI_WHISPER ? 1e-10f : p.amin);
+      outv = log_epilogue<EPI>(p, m);
+      // positive floats order like their bit patterns; a NaN is the largest pattern
+      mhi = max(mhi, __builtin_bit_cast(unsigned, m));
+      mlo = min(mlo, __builtin_bit_cast(unsigned, m));
+    }
+    if (!MIA_DBG(p, 4)) *reinterpret_cast<float*>(rowp + voff) = outv;
+    voff += f4;
+  }
+  // after the wave's last emit (N = its number of emits)
+  template <int N>
+  __device__ __forceinline__ void end_of_sweep(std::integral_constant<int, N>) {}
+};
+template <int BANK, class Ctx>
+__device__ __forceinline__ void compiled_sweep(int wv, Ctx& c) {
+  if constexpr (BANK == 128) w400_sweep_128(wv, c);
+  if constexpr (BANK == 80) w400_sweep_80(wv, c);
+}
+template <int BANK>
+__device__ __forceinline__ int compiled_first_filter(int wv) {
+  return BANK == 128 ? kW400Start128[wv] : kW400Start80[wv];
+}
+
 // Four consecutive samples.  Clips need not start on a 16-byte boundary (odd clip
 // lengths): the type only promises float alignment.
 struct __attribute__((packed, aligned(4))) float4_a4 {
@@ -215,7 +276,7 @@ __device__ __forceinline__ void wave_stage(float* __restrict__ stage, const Stag
   }
 }
 
-template <int EPI>
+template <int EPI, int BANK>
 __global__ __launch_bounds__(w400::WG, 4) void logmel400_kernel(
     FwdParams p, const float* __restrict__ g_y, const float* __restrict__ g_win,
     const float2* __restrict__ g_tw, const int* __restrict__ g_meta,
@@ -235,10 +296,15 @@ __global__ __launch_bounds__(w400::WG, 4) void logmel400_kernel(
   if (first >= last) return;
 
   // ---- mel sweep constants of this wave -------------------------------------------
-  const int* __restrict__ meta = g_meta + 16 * wv;
-  const int klo = meta[0], nchunks = meta[1], m0 = meta[2], npre = meta[3];
-  const float4* __restrict__ prog =
-      reinterpret_cast<const float4*>(g_sw) + wv * (W400_MEL_MAXC * W400_MEL_REC / 4);
+  int klo = 0, nchunks = 0, m0 = 0, npre = 0;
+  const float4* __restrict__ prog = nullptr;
+  if (BANK == 0) {
+    const int* __restrict__ meta = g_meta + 16 * wv;
+    klo = meta[0], nchunks = meta[1], m0 = meta[2], npre = meta[3];
+    prog = reinterpret_cast<const float4*>(g_sw) + wv * (W400_MEL_MAXC * W400_MEL_REC / 4);
+  } else {
+    m0 = compiled_first_filter<BANK>(wv);
+  }
 
   // ---- FFT constants of this lane's role: window taps t + 16 r and the step
   // twiddles exp(-2 pi i t k / 400), held in VGPRs for the whole run of tiles -------
@@ -289,6 +355,7 @@ __global__ __launch_bounds__(w400::WG, 4) void logmel400_kernel(
     const int lane = tid & 63;
     const int role = lane & 15;  // pass 1: role t; pass 2: butterfly k1
     const int fi = lane >> 4;    // frame of the wave's four
+    STAMP_DECL
     STAMP(0)
 
     // ---- fetch the next tile's samples; they land during the FFT --------------------------
@@ -296,7 +363,7 @@ __global__ __launch_bounds__(w400::WG, 4) void logmel400_kernel(
 #pragma unroll
     for (int i = 0; i < NQ4; ++i) regs.q[i] = {0.0f, 0.0f, 0.0f, 0.0f};  // defined on every path
     regs.h = {0.0f, 0.0f};
-    if (more) {
+    if (more && !MIA_DBG(p, 16)) {  // (ablation bit 16: no global loads)
       const float* __restrict__ ynb = g_y + (long long)cur_b * p.T;  // cur_* already advanced
       const long long sn = (long long)cur_tile * (FT * HOP) - p.pad + 4 * wv * HOP;
       wave_fetch(regs, ynb, p.T, sn, p.pad_mode, lane);
@@ -323,9 +390,14 @@ __global__ __launch_bounds__(w400::WG, 4) void logmel400_kernel(
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        rdft25(x, y);
+        if (MIA_DBG(p, 2)) {  // ablation: no pass-1 arithmetic
 #pragma unroll
-        for (int k = 1; k < 13; ++k) y[k] = cmul(y[k], twd[k]);
+          for (int k = 0; k < 13; ++k) y[k] = {x[2 * k], x[(2 * k + 1) % 25]};
+        } else {
+          rdft25(x, y);
+#pragma unroll
+          for (int k = 1; k < 13; ++k) y[k] = cmul(y[k], twd[k]);
+        }
         float2* __restrict__ exw = reinterpret_cast<float2*>(exf + 26 * role);
 #pragma unroll
         for (int c = 0; c < 13; ++c) exw[c] = y[c];
@@ -343,7 +415,7 @@ __global__ __launch_bounds__(w400::WG, 4) void logmel400_kernel(
         const float2* __restrict__ exr = reinterpret_cast<const float2*>(exf + 2 * k1r);
 #pragma unroll
         for (int q = 0; q < 16; ++q) v[q] = exr[13 * q];
-        Dft<16>::run(v);
+        if (!MIA_DBG(p, 2)) Dft<16>::run(v);  // (ablation: no pass-2 arithmetic)
 #pragma unroll
         for (int k2 = 0; k2 < 16; ++k2) pw[k2] = fmaf(v[k2].x, v[k2].x, v[k2].y * v[k2].y);
       }
@@ -382,7 +454,15 @@ __global__ __launch_bounds__(w400::WG, 4) void logmel400_kernel(
       const float* __restrict__ P = lds + (it & 1) * (SL + SC);
       // wave-uniform row pointer + lane offset: the row step is scalar arithmetic
       float* __restrict__ rowp = g_out + (((long long)b * p.n_mels + m0) * p.F + f0);
-      if (f0 + FT <= p.F) {
+      if (BANK != 0) {
+        if (valid) {  // lanes past the clip's last frame sit the sweep out
+          SweepCtx<EPI> c{p, P + (lane >> 2) * PW + (lane & 3), reinterpret_cast<char*>(rowp),
+                          4u * (unsigned)lane, 4u * (unsigned)p.F, mhi, mlo};
+          compiled_sweep<BANK>(wv, c);
+          mhi = c.mhi;
+          mlo = c.mlo;
+        }
+      } else if (f0 + FT <= p.F) {
         mel_sweep<EPI, true>(p, P, prog, klo, nchunks, npre, rowp, lane, true, mhi, mlo);
       } else {
         mel_sweep<EPI, false>(p, P, prog, klo, nchunks, npre, rowp, lane, valid, mhi, mlo);
@@ -413,6 +493,408 @@ __global__ __launch_bounds__(w400::WG, 4) void logmel400_kernel(
     // the lanes that transform them --------------------------------------------------------
     if (more) wave_stage(mine + ((it + 1) & 1) * SL, regs, lane);
     STAMP(7)
+    STAMP_FLUSH
+  }
+}
+
+
+// =============================================================================================
+// The same front-end with the samples brought into LDS by LDS-DMA loads (global_load_lds_dwordx4)
+// instead of through registers, for the compiled filterbanks and clips whose rows are 16-byte
+// aligned.  Differences from logmel400_kernel:
+//   * a wave's 880 samples have a FIXED staging area of their own at the end of the wave's
+//     region (it doubles as the exchange area of frames 2, 3), so the loads of tile i + 1 can be
+//     issued as soon as pass 2 of tile i has read its exchange back - before the barrier and
+//     before the sweep's stores, which therefore never stand in front of a load in the
+//     vector-memory queue; no staging registers, no ds_write pass;
+//   * bank conflicts between the two frames of a half-wave are avoided by an XOR swizzle
+//     (bit 4 of the position of every sample in an even 160-sample row) that is applied to
+//     the SOURCE address of each DMA lane; the reading lanes fold it into their offsets;
+//   * the workgroup barrier is a bare s_barrier (a __syncthreads() would drain the loads in
+//     flight), and the wait for the DMA sits at the end of the sweep, counted so that the
+//     sweep's own stores stay in flight.
+// Arithmetic, its order and the output are bit-identical to logmel400_kernel.
+namespace w400d {
+constexpr int N = 400, HOP = 160, FT = 64, NW = W400_WAVES, WG = NW * 64;
+constexpr int BINS = N / 2 + 1;
+constexpr int EXF = 16 * 26;       // exchange dwords per frame: 16 roles x 13 complex
+constexpr int SL = 2 * EXF;        // power slot (4 x 201 used) = exchange of frames 0, 1
+constexpr int WSPAN = 3 * HOP + N; // 880 samples under a wave's 4 frames
+constexpr int ST = WSPAN + 4;      // staging area = exchange of frames 2, 3 (the + 4: PW = 4 mod 8)
+constexpr int PW = 2 * SL + ST;    // per-wave region: slot 0 | slot 1 | staging
+constexpr int OFF_ST = 2 * SL;
+constexpr int NDMA = (WSPAN / 4 + 63) / 64;        // 4 wave-wide 16-byte loads
+constexpr int LAST_LANES = WSPAN / 4 - 64 * (NDMA - 1);  // lanes of the last one (28)
+static_assert(ST >= 2 * EXF && SL >= 4 * BINS, "areas hold either content");
+static_assert(PW % 8 == 4, "mel reads of 8 waves' regions hit 32 different banks");
+static_assert((PW * 4) % 16 == 0 && (OFF_ST * 4) % 16 == 0, "DMA destinations are 16-byte aligned");
+static_assert(NW * PW * 4 <= 160 * 1024, "LDS budget");
+static_assert(EXF % 64 == 32, "frames 0/1 of a half-wave read opposite bank halves");
+// position of sample s of the wave's span in the staging area, and back (an involution)
+__device__ __forceinline__ int swz(int s) { return s ^ (((s / HOP) & 1) ? 0 : 16); }
+}  // namespace w400d
+
+// One wave-wide LDS-DMA load: lane L's 16 bytes at gbase + voff land at lds_byte_addr + 16 L.
+// The compiler does not count this load (its s_waitcnt bookkeeping never sees it): the
+// caller waits for it with wait_vmcnt<N>().
+__device__ __forceinline__ void lds_dma16(const float* gbase, unsigned voff_bytes,
+                                          unsigned lds_byte_addr) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %3\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %2\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff_bytes), "s"(gbase), "s"(lds_byte_addr)
+      : "memory");
+}
+// The same with a per-lane 64-bit source address.
+__device__ __forceinline__ void lds_dma16_ptr(const float* gptr, unsigned lds_byte_addr) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gptr), "s"(lds_byte_addr)
+      : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory");
+}
+// SW_END of the generated sweeps: every older vector-memory operation than the wave's
+// last N (the stores of its sweep) is complete - in particular the next tile's DMA.
+// Sweep context of the DMA kernel.  Its stores cover whole 128-byte lines: output rows
+// start at arbitrary 4-byte phases (a row is F floats), so for row j the wave does not store
+// the tile's 64 frames but the 64 frames that start sg_j = (row start + tile start) mod 32
+// frames earlier, where that window begins on a line boundary.  The first sg_j of them are
+// the last outputs of the previous tile, kept in prev[j]; a lane rotation (ds_bpermute)
+// brings every value to the lane that stores it.  The first tile of a clip (or of the
+// workgroup's run) has no predecessor and skips those lanes; the last one also stores the
+// frames its window leaves over.  Unaligned 256-byte pieces cost 18 % of the step: partial
+// lines are written to memory as read-modify-write pairs.
+template <int EPI, int MAXR, bool FULL>
+struct SweepCtxDma {
+  const FwdParams& p;
+  const float* __restrict__ pr;  // this lane's column of the power tile
+  char* __restrict__ rowp;       // wave-uniform: 32 floats before row 0 of the wave, frame f0
+  float (&prev)[MAXR];           // the previous tile's outputs of this lane's frame slot
+  unsigned lane4;                // 4 * lane
+  unsigned mhi, mlo;             // bit patterns of the largest / smallest floored power
+  unsigned sg4;                  // wave-uniform: 4 * frames the next row's window starts early (0..31)
+  unsigned fm4;                  // 4 * (F mod 32): sg4's step from row to row
+  unsigned roff;                 // wave-uniform: byte offset of the next row from rowp, + 128
+  unsigned f4;                   // one row in bytes
+  // FULL: the tile has a predecessor in this wave's run, 64 frames of its clip, and is not
+  // the last of the clip or the run - every lane stores, nothing is left over.
+  int has_prev, flush, nvalid;   // (!FULL) wave-uniform; frames of the clip in this tile
+  float pend_y;                  // (FULL) the previous emit's rotated value, stored one emit
+  unsigned pend_off;             // later so that the rotation's latency is not waited for
+  __device__ __forceinline__ float ld(int k) const { return pr[4 * k]; }
+  __device__ __forceinline__ void store(unsigned off, float v) const {
+    if (!MIA_DBG(p, 4)) *reinterpret_cast<float*>(rowp + (size_t)off) = v;
+  }
+  template <int J>
+  __device__ __forceinline__ void emit(std::integral_constant<int, J>, float acc) {
+    static_assert(J < MAXR, "row index within the wave");
+    // max(acc, 1e-10) that keeps a NaN: acc is a sum of products of non-negative numbers,
+    // so it is +0, positive or NaN, and those order like their bit patterns
+    const unsigned mb = max(__builtin_bit_cast(unsigned, acc), __builtin_bit_cast(unsigned, 1e-10f));
+    const float outv = log_epilogue<EPI>(p, __builtin_bit_cast(float, mb));
+    mhi = max(mhi, mb);
+    mlo = min(mlo, mb);
+    // value for window position (lane + sg) mod 64: this tile's frame, or for the last sg
+    // lanes the previous tile's
+    const float x = lane4 < 256u - sg4 ? outv : prev[J];
+    prev[J] = outv;
+    const unsigned t = lane4 - sg4;  // byte offset of this lane's window slot from f0
+    const float y = __builtin_bit_cast(
+        float, __builtin_amdgcn_ds_bpermute((int)(t & 252u), __builtin_bit_cast(int, x)));
+    const unsigned off = t + roff;
+    if (FULL) {
+      if (J > 0) store(pend_off, pend_y);
+      pend_y = y;
+      pend_off = off;
+    } else {
+      const int l = (int)(lane4 >> 2), sg = (int)(sg4 >> 2);
+      if ((has_prev || l >= sg) && l - sg < nvalid) store(off, y);
+      if (flush) {  // frames 64 - sg .. nvalid - 1 of the tile: this tile's values of lanes 64 - sg + l
+        const float y2 = __builtin_bit_cast(
+            float, __builtin_amdgcn_ds_bpermute((int)(t & 252u), __builtin_bit_cast(int, outv)));
+        if (l < nvalid - 64 + sg) store(off + 256u, y2);
+      }
+    }
+    roff += f4;
+    sg4 = (sg4 + fm4) & 124u;
+  }
+  template <int N>
+  __device__ __forceinline__ void end_of_sweep(std::integral_constant<int, N>) {
+    // The next tile's DMA is older than this sweep's stores; in a full tile there are N of
+    // them, otherwise (masked or doubled stores) wait for everything.
+    if (FULL) {
+      if (N > 0) store(pend_off, pend_y);
+      wait_vmcnt<N>();
+    } else {
+      wait_vmcnt<0>();
+    }
+  }
+};
+
+// Issue the loads of the wave's 880 samples starting at sample s_wave of clip row yb.
+__device__ __forceinline__ void dma_wave_samples(const float* __restrict__ yb, long long T,
+                                                 long long s_wave, int pad_mode, int lane,
+                                                 const unsigned (&soff)[w400d::NDMA],
+                                                 float* __restrict__ stage, unsigned stage_bytes) {
+  using namespace w400d;
+  if (s_wave >= 0 && s_wave + WSPAN <= T) {  // wave-uniform: the whole span lies inside the clip
+    const float* __restrict__ gbase = yb + s_wave;
+#pragma unroll
+    for (int i = 0; i < NDMA - 1; ++i) lds_dma16(gbase, 4u * soff[i], stage_bytes + 1024u * i);
+    if (lane < LAST_LANES) lds_dma16(gbase, 4u * soff[NDMA - 1], stage_bytes + 1024u * (NDMA - 1));
+  } else {
+    // a clip boundary inside the span: lanes whose four samples exist load them, the others
+    // build theirs by the padding rule and write them
+#pragma unroll
+    for (int i = 0; i < NDMA; ++i) {
+      const int pos = 4 * (lane + 64 * i);
+      if (pos < WSPAN) {
+        const long long a = s_wave + (long long)soff[i];
+        if (a >= 0 && a + 4 <= T) {
+          lds_dma16_ptr(yb + a, stage_bytes + 1024u * i);
+        } else {
+          const float4 v = {fetch_sample(yb, T, a, pad_mode), fetch_sample(yb, T, a + 1, pad_mode),
+                            fetch_sample(yb, T, a + 2, pad_mode), fetch_sample(yb, T, a + 3, pad_mode)};
+          *reinterpret_cast<float4*>(stage + pos) = v;
+        }
+      }
+    }
+  }
+}
+
+template <int EPI, int BANK>
+__global__ __launch_bounds__(w400d::WG, 4) void logmel400d_kernel(
+    FwdParams p, const float* __restrict__ g_y, const float* __restrict__ g_win,
+    const float2* __restrict__ g_tw, float* __restrict__ g_out, int* __restrict__ g_maxkey,
+    int* __restrict__ g_minkey) {
+  using namespace w400d;
+  static_assert(BANK != 0, "the DMA kernel exists for the compiled filterbanks");
+  __shared__ __attribute__((aligned(16))) float lds[NW * PW];
+
+  const int tid0 = threadIdx.x;
+  const int wv = __builtin_amdgcn_readfirstlane(tid0 >> 6);  // wave: frames 4 wv .. 4 wv + 3
+  const int total = (int)(p.B * p.tiles);  // launcher guarantees < 2^31
+  const int first = (int)blockIdx.x * p.tiles_per_wg;
+  const int last = min(first + p.tiles_per_wg, total);
+  if (first >= last) return;
+  const int m0 = compiled_first_filter<BANK>(wv);
+
+  // ---- per-lane constants, held in VGPRs for the whole run of tiles ----------------------
+  const int role0 = tid0 & 15;
+  float wnd[25];
+  float2 twd[13];
+#pragma unroll
+  for (int r = 0; r < 25; ++r) wnd[r] = g_win[32 * role0 + r];
+#pragma unroll
+  for (int k = 1; k < 13; ++k) twd[k] = g_tw[16 * role0 + k];
+  unsigned soff[NDMA];  // sample (relative to the wave's span) behind this lane's DMA chunks
+#pragma unroll
+  for (int i = 0; i < NDMA; ++i) {
+    const int pos = 4 * ((tid0 & 63) + 64 * i);
+    soff[i] = (unsigned)swz(pos < WSPAN ? pos : 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 25; ++r) asm volatile("" : "+v"(wnd[r]));
+#pragma unroll
+  for (int k = 1; k < 13; ++k) asm volatile("" : "+v"(twd[k].x), "+v"(twd[k].y));
+#pragma unroll
+  for (int i = 0; i < NDMA; ++i) asm volatile("" : "+v"(soff[i]));
+
+  int cur_b = first / p.tiles;
+  int cur_tile = first - cur_b * p.tiles;
+  unsigned mhi = 0u, mlo = 0x7F800000u;
+  constexpr int MAXR = BANK == 128 ? W400_BANK128_MAXROWS : W400_BANK80_MAXROWS;
+  float prev[MAXR];  // the previous tile's outputs (see SweepCtxDma)
+#pragma unroll
+  for (int j = 0; j < MAXR; ++j) prev[j] = 0.0f;
+  float* __restrict__ mine = lds + wv * PW;  // slot 0 | slot 1 | staging
+  float* __restrict__ stage = mine + OFF_ST;
+  const unsigned stage_bytes = (unsigned)__builtin_amdgcn_readfirstlane(
+      (int)(unsigned)(unsigned long long)(stage));  // LDS byte address (low half of the flat one)
+
+  // ---- the first tile's samples --------------------------------------------------------
+  dma_wave_samples(g_y + (long long)cur_b * p.T, p.T,
+                   (long long)cur_tile * (FT * HOP) - p.pad + 4 * wv * HOP, p.pad_mode, tid0 & 63,
+                   soff, stage, stage_bytes);
+  wait_vmcnt<0>();
+
+  int it = 0;
+  for (int idx = first; idx < last; ++idx, ++it) {
+    const int b = cur_b;
+    const int tile = cur_tile;
+    if (++cur_tile == p.tiles) {
+      cur_tile = 0;
+      ++cur_b;
+    }
+    const bool more = idx + 1 < last;
+    int tid = tid0;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63;
+    const int role = lane & 15;  // pass 1: role t; pass 2: butterfly k1
+    const int fi = lane >> 4;    // frame of the wave's four
+    STAMP_DECL
+    STAMP(0)
+    STAMP(1)
+
+    float* __restrict__ slot = mine + (it & 1) * SL;
+    {
+      // exchange area of this lane's frame: frames 0, 1 in the slot, 2, 3 in the staging area
+      float* __restrict__ exf = (fi < 2 ? slot : stage - 2 * EXF) + EXF * fi;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      // ---- pass 1: real radix-25 over x[t + 16 r] of frame 4 wv + fi, then the step twiddle --
+      {
+        float2 y[13];
+        float x[25];
+        // sample 160 fi + t + 16 r sits at 160 fi + t + 16 (r ^ e), e = 1 in the even rows
+        // fi + r / 10 of the span (the swizzle)
+        const int sel = (fi & 1) ^ 1;
+        const float* __restrict__ sp = stage + HOP * fi + role;
+        const float* __restrict__ spp = sp + 16 * sel;
+        const float* __restrict__ spm = sp - 16 * sel;
+#pragma unroll
+        for (int r = 0; r < 25; ++r) {
+          const int u = r ^ ((r / 10) & 1);
+          x[r] = ((u & 1) ? spm : spp)[16 * u] * wnd[r];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (MIA_DBG(p, 2)) {
+#pragma unroll
+          for (int k = 0; k < 13; ++k) y[k] = {x[2 * k], x[(2 * k + 1) % 25]};
+        } else {
+          rdft25(x, y);
+#pragma unroll
+          for (int k = 1; k < 13; ++k) y[k] = cmul(y[k], twd[k]);
+        }
+        float2* __restrict__ exw = reinterpret_cast<float2*>(exf + 26 * role);
+#pragma unroll
+        for (int c = 0; c < 13; ++c) exw[c] = y[c];
+      }
+      STAMP(2)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+
+      // ---- pass 2: radix-16 over the roles; v[k2] = X[k1 + 25 k2] ---------------------------
+      float pw[16];
+      {
+        float2 v[16];
+        const int k1r = role < 13 ? role : 12;
+        const float2* __restrict__ exr = reinterpret_cast<const float2*>(exf + 2 * k1r);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = exr[13 * q];
+        if (!MIA_DBG(p, 2)) Dft<16>::run(v);
+#pragma unroll
+        for (int k2 = 0; k2 < 16; ++k2) pw[k2] = fmaf(v[k2].x, v[k2].x, v[k2].y * v[k2].y);
+      }
+      // opaque: the exchange has been read back (the power values depend on it) before
+      // anything below is issued
+#pragma unroll
+      for (int k2 = 0; k2 < 16; ++k2) asm volatile("" : "+v"(pw[k2]));
+      STAMP(3)
+
+      // ---- the next tile's samples: the staging area is free from here on ------------------
+      if (more && !MIA_DBG(p, 16)) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        dma_wave_samples(g_y + (long long)cur_b * p.T, p.T,
+                         (long long)cur_tile * (FT * HOP) - p.pad + 4 * wv * HOP, p.pad_mode, lane,
+                         soff, stage, stage_bytes);
+      }
+
+      // ---- power columns of the wave's 4 frames: slot[4 * bin + fi] -------------------------
+      if (role < 13) {
+        float* __restrict__ pa = slot + 4 * role + fi;          // bins k1 + 25 k2, k2 = 0..7
+        float* __restrict__ pb = slot + 4 * (200 - role) + fi;  // bins 400 - (k1 + 25 k2), k2 = 8..15
+#pragma unroll
+        for (int k2 = 0; k2 < 8; ++k2) pa[4 * 25 * k2] = pw[k2];
+        pb[0] = pw[8];
+        if (role != 0) {  // butterfly 0 repeats bins 175, 150, ... it already wrote
+#pragma unroll
+          for (int k2 = 9; k2 < 16; ++k2) pb[-4 * 25 * (k2 - 8)] = pw[k2];
+        }
+      }
+    }
+    STAMP(4)
+    // The power of this tile is complete, and every wave is done with the previous sweep.
+    // A bare barrier: the DMA stays in flight across it.
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    STAMP(5)
+
+    // ---- mel sweep + log epilogue (lane = frame) --------------------------------------------
+    {
+      const long long f0 = (long long)tile * FT;
+      const bool valid = f0 + lane < p.F;
+      const float* __restrict__ P = lds + (it & 1) * SL;
+      float* __restrict__ rowp = g_out + (((long long)b * p.n_mels + m0) * p.F + f0);
+      if (!MIA_DBG(p, 1)) {
+        const long long row0 = (long long)b * p.n_mels + m0;
+        const int has_prev = tile > 0 && idx > first;
+        const int flush = cur_tile == 0 || !more;  // last tile of the clip or of the run
+        const int nvalid = p.F - f0 < FT ? (int)(p.F - f0) : FT;
+        const int full = has_prev && !flush && nvalid == FT;
+        const unsigned mhi0 = mhi, mlo0 = mlo;
+        const float* __restrict__ pcol = P + (lane >> 2) * PW + (lane & 3);
+        char* __restrict__ rp = reinterpret_cast<char*>(rowp - 32);
+        const unsigned sg0 = 4u * (unsigned)((row0 * p.F) & 31), fm = 4u * (unsigned)(p.F & 31);
+        const unsigned f4 = 4u * (unsigned)p.F;
+        unsigned nhi, nlo;
+        if (full) {
+          SweepCtxDma<EPI, MAXR, true> c{p, pcol, rp, prev, 4u * (unsigned)lane, mhi, mlo, sg0, fm, 128u,
+                                         f4, 1, 0, FT, 0.0f, 0u};
+          compiled_sweep<BANK>(wv, c);
+          nhi = c.mhi;
+          nlo = c.mlo;
+        } else {
+          SweepCtxDma<EPI, MAXR, false> c{p, pcol, rp, prev, 4u * (unsigned)lane, mhi, mlo, sg0, fm, 128u,
+                                          f4, has_prev, flush, nvalid, 0.0f, 0u};
+          compiled_sweep<BANK>(wv, c);
+          nhi = c.mhi;
+          nlo = c.mlo;
+        }
+        // lanes past the clip's last frame swept padding: they do not count
+        mhi = valid ? nhi : mhi0;
+        mlo = valid ? nlo : mlo0;
+      } else {
+        wait_vmcnt<0>();  // no sweep, no stores: the DMA is the youngest operation
+      }
+      if (EPI != MIA_EPI_NONE && g_maxkey != nullptr && (cur_tile == 0 || !more)) {
+        unsigned rhi = mhi, rlo = mlo;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+          rhi = max(rhi, (unsigned)__shfl_xor((int)rhi, off));
+          rlo = min(rlo, (unsigned)__shfl_xor((int)rlo, off));
+        }
+        if (lane == 0 && rhi != 0u) {
+          float rmax = log_epilogue<EPI>(p, __builtin_bit_cast(float, rhi));
+          const float rmin = log_epilogue<EPI>(p, __builtin_bit_cast(float, rlo));
+          if (EPI == MIA_EPI_WHISPER) rmax = fmaf(rmax, 4.0f, -4.0f);
+          atomicMax(g_maxkey + b, float_to_key_nan(rmax));
+          atomicMin(g_minkey + b, float_to_key(rmin));
+        }
+        mhi = 0u;
+        mlo = 0x7F800000u;
+      }
+    }
+    STAMP(6)
+    STAMP(7)
+    STAMP_FLUSH
   }
 }
 
@@ -421,6 +903,40 @@ extern "C" void mia_debug_set_buffer(void* ptr) {
   (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dbgbuf), &ptr, sizeof(ptr));
 }
 #endif
+
+// 80 / 128 if `basis` (n_mels x bins) equals that compiled-in Whisper bank bit for bit, else 0.
+int w400_compiled_bank(const float* basis, int n_mels, int bins) {
+  if (bins != w400::BINS || (n_mels != 80 && n_mels != 128)) return 0;
+  const int nnz = n_mels == 128 ? W400_BANK128_NNZ : W400_BANK80_NNZ;
+  const unsigned short(*idx)[2] = n_mels == 128 ? kW400Bank128Idx : kW400Bank80Idx;
+  const unsigned* bits = n_mels == 128 ? kW400Bank128Bits : kW400Bank80Bits;
+  int seen = 0;
+  for (int m = 0; m < n_mels; ++m) {
+    for (int k = 0; k < bins; ++k) {
+      const unsigned b = __builtin_bit_cast(unsigned, basis[(size_t)m * bins + k]);
+      if (seen < nnz && idx[seen][0] == m && idx[seen][1] == k) {
+        if (b != bits[seen]) return 0;
+        ++seen;
+      } else if ((b & 0x7FFFFFFFu) != 0u) {  // a non-zero the compiled bank does not have
+        return 0;
+      }
+    }
+  }
+  return seen == nnz ? n_mels : 0;
+}
+
+template <int EPI, int BANK>
+static void launch_w400d(const FwdParams& p, const W400Tables& tb, unsigned grid, hipStream_t s) {
+  hipLaunchKernelGGL((logmel400d_kernel<EPI, BANK>), dim3(grid), dim3(w400d::WG), 0, s, p, p.y,
+                     tb.win16, tb.tw16, p.mout, p.clip_max_key, p.clip_min_key);
+}
+
+template <int EPI, int BANK>
+static void launch_w400(const FwdParams& p, const W400Tables& tb, unsigned grid, hipStream_t s) {
+  hipLaunchKernelGGL((logmel400_kernel<EPI, BANK>), dim3(grid), dim3(w400::WG), 0, s, p, p.y,
+                     tb.win16, tb.tw16, tb.sweep_meta, tb.sweep_w, p.mout, p.clip_max_key,
+                     p.clip_min_key);
+}
 
 int launch_logmel400(const FwdParams& p0, const W400Tables& tb, hipStream_t s) {
   FwdParams p = p0;
@@ -434,26 +950,27 @@ int launch_logmel400(const FwdParams& p0, const W400Tables& tb, hipStream_t s) {
   // Persistent grid: one workgroup per CU (158 KB of LDS), each walking a
   // contiguous run of tiles (consecutive tiles of a clip share cache lines of the
   // output rows, so one workgroup - one L2 - writes both halves of each line).
-  int dev = 0, cus = 256;
-  if (hipGetDevice(&dev) == hipSuccess) {
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-  }
-  long long grid = 1LL * cus;
+  long long grid = tb.cus > 0 ? tb.cus : 256;  // the plan's device
   if (grid > total) grid = total;
   p.tiles_per_wg = (int)((total + grid - 1) / grid);
   grid = (total + p.tiles_per_wg - 1) / p.tiles_per_wg;
-  if (p.epi == MIA_EPI_WHISPER) {
-    hipLaunchKernelGGL(logmel400_kernel<MIA_EPI_WHISPER>, dim3((unsigned)grid), dim3(w400::WG), 0,
-                       s, p, p.y, tb.win16, tb.tw16, tb.sweep_meta, tb.sweep_w, p.mout,
-                       p.clip_max_key, p.clip_min_key);
+  // The straight-line sweep exists for Whisper's two banks with the Whisper epilogue.
+  const int bank = (p.epi == MIA_EPI_WHISPER && !tb.force_table_sweep) ? tb.compiled_bank : 0;
+  // LDS-DMA staging needs 16-byte aligned sources: every clip row must start on one.
+  const bool dma = bank != 0 && !tb.force_vgpr_staging &&
+                   (reinterpret_cast<unsigned long long>(p.y) & 15ull) == 0 && p.T % 4 == 0 &&
+                   p.pad % 4 == 0;
+  if (dma) {
+    if (bank == 128) launch_w400d<MIA_EPI_WHISPER, 128>(p, tb, (unsigned)grid, s);
+    else launch_w400d<MIA_EPI_WHISPER, 80>(p, tb, (unsigned)grid, s);
+  } else if (p.epi == MIA_EPI_WHISPER) {
+    if (bank == 128) launch_w400<MIA_EPI_WHISPER, 128>(p, tb, (unsigned)grid, s);
+    else if (bank == 80) launch_w400<MIA_EPI_WHISPER, 80>(p, tb, (unsigned)grid, s);
+    else launch_w400<MIA_EPI_WHISPER, 0>(p, tb, (unsigned)grid, s);
   } else if (p.epi == MIA_EPI_DB) {
-    hipLaunchKernelGGL(logmel400_kernel<MIA_EPI_DB>, dim3((unsigned)grid), dim3(w400::WG), 0, s,
-                       p, p.y, tb.win16, tb.tw16, tb.sweep_meta, tb.sweep_w, p.mout,
-                       p.clip_max_key, p.clip_min_key);
+    launch_w400<MIA_EPI_DB, 0>(p, tb, (unsigned)grid, s);
   } else {
-    hipLaunchKernelGGL(logmel400_kernel<MIA_EPI_NONE>, dim3((unsigned)grid), dim3(w400::WG), 0, s,
-                       p, p.y, tb.win16, tb.tw16, tb.sweep_meta, tb.sweep_w, p.mout,
-                       p.clip_max_key, p.clip_min_key);
+    launch_w400<MIA_EPI_NONE, 0>(p, tb, (unsigned)grid, s);
   }
   MIA_CHECK_HIP(hipGetLastError());
   return MIA_OK;

@@ -96,6 +96,10 @@ struct mia_plan {
   float2* d_tw16 = nullptr;      // [16][16] exp(-2 pi i t k1 / 400), k1 = 0..12 used
   int* d_sweep_meta = nullptr;   // [16][16] per-wave sweep header: first bin, chunks, first filter, pre-emits
   float* d_sweep_w = nullptr;    // [16][W400_MEL_MAXC][32] per-wave sweep program (see logmel400.hip)
+  int w400_bank = 0;             // 80 / 128 when the filterbank is that compiled-in Whisper bank
+  int cus = 256;                 // compute units of the device (sizes the persistent grids)
+  int opt_table_sweep = 0;       // mia_plan_set_option("w400_table_sweep"): ablation / test knob
+  int opt_vgpr_staging = 0;      // mia_plan_set_option("w400_vgpr_staging"): ablation / test knob
 };
 
 namespace mia {
@@ -141,6 +145,10 @@ struct W400Tables {
   const float2* tw16;
   const int* sweep_meta;
   const float* sweep_w;
+  int compiled_bank;      // 80 / 128: the filterbank equals that compiled-in Whisper bank; else 0
+  int force_table_sweep;  // testing: take the table-driven sweep although a compiled one exists
+  int force_vgpr_staging; // testing: stage the samples through registers, not by LDS-DMA
+  int cus;                // compute units of the plan's device
 };
 
 struct InvParams {
@@ -164,6 +172,7 @@ bool istft_fused_supported(int n_fft, int hop);
 int launch_istft_fused(const mia_plan* plan, const InvParams& p, hipStream_t s);
 int launch_init_keys(int* max_keys, int* min_keys, long long n, hipStream_t s);
 int launch_logmel400(const FwdParams& p, const W400Tables& tb, hipStream_t s);
+int w400_compiled_bank(const float* basis, int n_mels, int bins);
 bool fft_size_supported(int n_fft);
 int forward_tile_frames(int n_fft, int mode);
 

@@ -134,3 +134,23 @@ def test_null_plan_is_rejected_without_touching_a_gpu():
     assert lib.mia_stft(None, None, 1, 1, 1.0, None, None) == _lib.MIA_ERR_INVALID
     assert lib.mia_melspectrogram(None, None, 1, 1, 0, 1.0, 1e-10, 10.0, 80.0, 0, None, None, 0,
                                   None) == _lib.MIA_ERR_INVALID
+
+
+def test_compiled_whisper_banks_are_current_and_bit_exact():
+    """The generated sweep of the n_fft = 400 kernel is built from the same filterbank
+    arithmetic as mia_mel_filterbank, and the file on disk is what the generator writes."""
+    import importlib.util
+    import os
+
+    from mlx_audio_amd.primitives.mel import mel_filterbank_np
+
+    path = os.path.join(os.path.dirname(__file__), "..", "mlx_audio_amd", "csrc",
+                        "gen_w400_sweep.py")
+    spec = importlib.util.spec_from_file_location("gen_w400_sweep", path)
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    for n_mels in gen.BANKS:
+        want = mel_filterbank_np(16000, 400, n_mels, 0.0, 8000.0, False, "slaney")
+        got = gen.filterbank(n_mels)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert gen.generate() == open(gen.OUT).read()

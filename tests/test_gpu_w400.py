@@ -1,0 +1,93 @@
+"""The n_fft = 400 kernel's compiled mel sweep (Whisper's 80- and 128-filter banks as
+straight-line code) against its table-driven sweep: the same bits, whichever path runs."""
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+from mlx_audio_amd import _lib  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def _plan(n_mels):
+    from mlx_audio_amd._runtime import get_plan
+    from mlx_audio_amd.primitives.mel import mel_filterbank_np
+    from mlx_audio_amd.primitives.windows import padded_window_np
+
+    basis = mel_filterbank_np(16000, 400, n_mels, 0.0, 8000.0, False, "slaney")
+    return get_plan(torch.device("cuda", 0), 400, 160, True, "constant",
+                    padded_window_np("hann", 400, 400), mel_basis=basis, power=2.0)
+
+
+def _logmel(plan, y, per_clip=1):
+    lib = _lib.lib()
+    B, T = y.shape
+    out = torch.empty((B, plan.n_mels, plan.num_frames(T)), dtype=torch.float32, device=y.device)
+    ws_bytes = lib.mia_mel_workspace_bytes(plan.handle, B, T)
+    ws = torch.empty((max(ws_bytes, 1),), dtype=torch.uint8, device=y.device)
+    _lib.check(lib.mia_melspectrogram(plan.handle, y.data_ptr(), B, T, _lib.EPI_WHISPER, 1.0, 1e-10,
+                                      10.0, -1.0, per_clip, out.data_ptr(), ws.data_ptr(), ws_bytes,
+                                      torch.cuda.current_stream(y.device).cuda_stream))
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
+@pytest.mark.parametrize("n_mels", [80, 128])
+def test_whisper_banks_take_the_compiled_sweep(n_mels):
+    plan = _plan(n_mels)
+    lib = _lib.lib()
+    assert lib.mia_plan_get_info(plan.handle, b"w400_tables") == 1
+    assert lib.mia_plan_get_info(plan.handle, b"w400_bank") == n_mels
+    assert lib.mia_plan_get_info(plan.handle, b"compute_units") > 0
+
+
+def test_other_banks_do_not():
+    from mlx_audio_amd._runtime import get_plan
+    from mlx_audio_amd.primitives.mel import mel_filterbank_np
+    from mlx_audio_amd.primitives.windows import padded_window_np
+
+    basis = mel_filterbank_np(16000, 400, 64, 20.0, 7600.0, False, "slaney")
+    plan = get_plan(torch.device("cuda", 0), 400, 160, True, "constant",
+                    padded_window_np("hann", 400, 400), mel_basis=basis, power=2.0)
+    assert _lib.lib().mia_plan_get_info(plan.handle, b"w400_bank") == 0
+
+
+@pytest.mark.parametrize("n_mels", [80, 128])
+@pytest.mark.parametrize("shape", [(3, 480000), (5, 16000), (2, 10239), (1, 160 * 64 * 3 - 200),
+                                   (300, 4000)])
+def test_compiled_sweep_equals_table_sweep(n_mels, shape):
+    plan = _plan(n_mels)
+    lib = _lib.lib()
+    g = torch.Generator(device="cuda").manual_seed(shape[0] * 1000 + n_mels)
+    y = torch.randn(shape, device="cuda", generator=g)
+    y[0, : shape[1] // 2] *= 1e-4  # a clip whose floor is active
+    if shape[0] > 1:
+        y[1] = 0.0  # silence
+    try:
+        for per_clip in (1, 0):
+            got = _logmel(plan, y, per_clip)
+            _lib.check(lib.mia_plan_set_option(plan.handle, b"w400_table_sweep", 1))
+            want = _logmel(plan, y, per_clip)
+            _lib.check(lib.mia_plan_set_option(plan.handle, b"w400_table_sweep", 0))
+            assert np.array_equal(got, want), (n_mels, shape, per_clip)
+    finally:
+        lib.mia_plan_set_option(plan.handle, b"w400_table_sweep", 0)
+
+
+def test_nan_and_inf_clips_compiled_sweep():
+    plan = _plan(128)
+    lib = _lib.lib()
+    g = torch.Generator(device="cuda").manual_seed(5)
+    y = torch.randn((4, 32000), device="cuda", generator=g)
+    y[1, 777] = float("nan")
+    y[2, 1234] = float("inf")
+    got = _logmel(plan, y)
+    _lib.check(lib.mia_plan_set_option(plan.handle, b"w400_table_sweep", 1))
+    try:
+        want = _logmel(plan, y)
+    finally:
+        lib.mia_plan_set_option(plan.handle, b"w400_table_sweep", 0)
+    assert np.array_equal(got, want, equal_nan=True)
+    assert np.isnan(got[1]).all() and np.isfinite(got[0]).all() and np.isfinite(got[3]).all()
