@@ -35,12 +35,13 @@ WAVES = 16
 BANKS = (80, 128)
 
 # Cost model of one wave's sweep, in issue slots: a bin costs its LDS read plus one slot
-# per non-zero weight; an emit costs floor + log (two slots) + scale + store + offset step
-# + the running extremes.
-COST_READ, COST_FMA, COST_EMIT = 1.0, 1.0, 7.0
+# per non-zero weight; an emit costs floor + log (two slots) + scale + the running extremes
+# + select, lane rotation and its address, store and its offset (the line-aligned stores).
+COST_READ, COST_FMA, COST_EMIT = 1.0, 1.0, float(os.environ.get("GEN_COST_EMIT", "7"))
+LOADS_FIRST = os.environ.get("GEN_LDFIRST", "0") == "1"
 # Waves 4 j .. 4 j + 3 are the j-th oldest on their SIMDs; the issue arbiter serves older
 # waves first, so the younger ones get a smaller share of the sweep.
-SHARE = (1.10, 1.05, 0.95, 0.90)
+SHARE = tuple(float(v) for v in os.environ.get("GEN_SHARE", "1.10,1.05,0.95,0.90").split(","))
 
 
 def _hz_to_mel(f: float) -> float:
@@ -203,9 +204,10 @@ def generate() -> str:
     L.append("//   python mlx_audio_amd/csrc/gen_w400_sweep.py")
     L.append("// The mel sweep of the n_fft = 400 kernel as straight-line code for Whisper's 80- and")
     L.append("// 128-filter banks.  The including file defines, for a context object c:")
-    L.append("//   SW_LD(k)        x = power of bin k of this lane's frame")
-    L.append("//   SW_MUL(a, w)    a = w * x          (first contribution to accumulator a)")
-    L.append("//   SW_FMA(a, w)    a = fma(w, x, a)")
+    L.append("//   SW_LD(x, k)       x = power of bin k of this lane's frame")
+    L.append("//   SW_SYNC()         every SW_LD of the wave has been issued")
+    L.append("//   SW_MUL(a, w, x)   a = w * x          (first contribution to accumulator a)")
+    L.append("//   SW_FMA(a, w, x)   a = fma(w, x, a)")
     L.append("//   SW_EMIT(j, a)   output row j of the wave is complete with value a")
     L.append("//   SW_EMIT0(j)     ... with value 0 (a filter between two bins)")
     L.append("//   SW_END(n)       the wave's sweep is over; it emitted n rows")
@@ -233,7 +235,6 @@ def generate() -> str:
         costs = []
         L.append("template <class Ctx>")
         L.append(f"__device__ __forceinline__ void w400_sweep_{n_mels}(int wv, Ctx& c) {{")
-        L.append("  float x;")
         L.append("  switch (wv) {")
         for w in range(WAVES):
             m0, m1 = starts[w], starts[w + 1]
@@ -241,14 +242,29 @@ def generate() -> str:
             costs.append(program_cost(prog))
             L.append(f"    case {w}: {{  // filters {m0}..{m1 - 1}, cost {costs[-1]:.0f}")
             accs = sorted({t[0] for st in prog if st[0] == "bin" for t in st[2]})
+            bins_w = [st[1] for st in prog if st[0] == "bin"]
+            if bins_w:
+                L.append("      float " + ", ".join(f"x{i}" for i in range(len(bins_w))) + ";")
             if accs:
                 L.append("      float " + ", ".join(f"a{a}" for a in accs) + ";")
+            # every power value of the wave's bins first (the reads are then all in flight
+            # together and the arithmetic waits for them in order), then the arithmetic
+            if LOADS_FIRST:
+                for i in range(0, len(bins_w), 6):
+                    L.append("      " + " ".join(f"SW_LD(x{i + j}, {k})"
+                                                 for j, k in enumerate(bins_w[i:i + 6])))
+                L.append("      SW_SYNC()")
+            ib = 0
             for st in prog:
                 if st[0] == "bin":
+                    if not LOADS_FIRST:
+                        L.append(f"      SW_LD(x{ib}, {st[1]})")
                     ops = " ".join(
-                        (f"SW_MUL(a{a}, {fhex(wt)})" if first else f"SW_FMA(a{a}, {fhex(wt)})")
+                        (f"SW_MUL(a{a}, {fhex(wt)}, x{ib})" if first
+                         else f"SW_FMA(a{a}, {fhex(wt)}, x{ib})")
                         for a, wt, first in st[2])
-                    L.append(f"      SW_LD({st[1]}) {ops}")
+                    L.append(f"      {ops}")
+                    ib += 1
                 else:
                     j = st[1] - m0
                     L.append(f"      SW_EMIT({j}, a{st[1]})" if st[2] else f"      SW_EMIT0({j})")

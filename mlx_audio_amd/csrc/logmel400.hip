@@ -37,9 +37,10 @@
 #include "fft_engine.h"
 #include "mia_internal.h"
 // the steps of the generated sweep programs, on a context object c (SweepCtx below)
-#define SW_LD(k) x = c.ld(k);
-#define SW_MUL(a, w) a = (w) * x;
-#define SW_FMA(a, w) a = fmaf((w), x, a);
+#define SW_LD(x, k) x = c.ld(k);
+#define SW_SYNC() __builtin_amdgcn_sched_barrier(0);
+#define SW_MUL(a, w, x) a = (w) * x;
+#define SW_FMA(a, w, x) a = fmaf((w), x, a);
 #define SW_EMIT(j, a) c.emit(std::integral_constant<int, (j)>{}, a);
 #define SW_EMIT0(j) c.emit(std::integral_constant<int, (j)>{}, 0.0f);
 #define SW_END(n) c.end_of_sweep(std::integral_constant<int, (n)>{});
@@ -71,8 +72,9 @@ static_assert(LDS_DWORDS * 4 <= 160 * 1024, "LDS budget");
 
 // Profiling hooks, compiled in only with -DMIA_DEBUG_HOOKS (tools/abl.sh, tools/stamps.py):
 // FwdParams::dbg bit 1 skips the mel sweep, bit 2 the FFT arithmetic (LDS traffic kept),
-// bit 4 the output stores, bit 16 the global loads, bit 8 enables the per-phase cycle
-// stamps of workgroup 77 (needs -DMIA_W400_STAMPS as well).
+// bit 4 the output stores, bit 16 the global loads, and in the DMA kernel bit 64 the
+// exchange through LDS, bit 128 the sample reads, bit 256 the power write; bit 8 enables
+// the per-phase cycle stamps of workgroup 77 (needs -DMIA_W400_STAMPS as well).
 #ifdef MIA_DEBUG_HOOKS
 #define MIA_DBG(p, bit) ((p).dbg & (bit))
 __device__ unsigned long long* g_dbgbuf = nullptr;
@@ -514,6 +516,12 @@ __global__ __launch_bounds__(w400::WG, 4) void logmel400_kernel(
 //     flight), and the wait for the DMA sits at the end of the sweep, counted so that the
 //     sweep's own stores stay in flight.
 // Arithmetic, its order and the output are bit-identical to logmel400_kernel.
+#ifndef W400D_SWEEP_PRIO
+#define W400D_SWEEP_PRIO 1
+#endif
+#ifndef W400D_STAGGER
+#define W400D_STAGGER 0
+#endif
 namespace w400d {
 constexpr int N = 400, HOP = 160, FT = 64, NW = W400_WAVES, WG = NW * 64;
 constexpr int BINS = N / 2 + 1;
@@ -726,175 +734,212 @@ __global__ __launch_bounds__(w400d::WG, 4) void logmel400d_kernel(
   const unsigned stage_bytes = (unsigned)__builtin_amdgcn_readfirstlane(
       (int)(unsigned)(unsigned long long)(stage));  // LDS byte address (low half of the flat one)
 
-  // ---- the first tile's samples --------------------------------------------------------
-  dma_wave_samples(g_y + (long long)cur_b * p.T, p.T,
-                   (long long)cur_tile * (FT * HOP) - p.pad + 4 * wv * HOP, p.pad_mode, tid0 & 63,
-                   soff, stage, stage_bytes);
-  wait_vmcnt<0>();
-
-  int it = 0;
-  for (int idx = first; idx < last; ++idx, ++it) {
-    const int b = cur_b;
-    const int tile = cur_tile;
-    if (++cur_tile == p.tiles) {
-      cur_tile = 0;
-      ++cur_b;
+  // Tiles k = 0 .. n - 1 of this workgroup's run; (b, tile) of tile k, k + 1 and k + 2.
+  const int n_run = last - first;
+  auto advance = [&](int& bb, int& tt) {
+    if (++tt == p.tiles) {
+      tt = 0;
+      ++bb;
     }
-    const bool more = idx + 1 < last;
+  };
+  // in period k: (b0, t0) is tile k, (b1, t1) tile k + 1, (b2, t2) tile k + 2; k starts at -1
+  int b0 = 0, t0 = 0;
+  int b1 = cur_b, t1 = cur_tile;
+  int b2 = b1, t2 = t1;
+  advance(b2, t2);
+
+  // ---- transform of tile kf (its samples are staged), P into slot[kf & 1]; issues the
+  // loads of tile kf + 1 = clip bn, tile tn ----------------------------------------------
+  auto transform = [&](int kf, bool load_next, int bn, int tn) {
     int tid = tid0;
     asm volatile("" : "+v"(tid));
     const int lane = tid & 63;
     const int role = lane & 15;  // pass 1: role t; pass 2: butterfly k1
     const int fi = lane >> 4;    // frame of the wave's four
-    STAMP_DECL
-    STAMP(0)
-    STAMP(1)
-
-    float* __restrict__ slot = mine + (it & 1) * SL;
+    float* __restrict__ slot = mine + (kf & 1) * SL;
+    // exchange area of this lane's frame: frames 0, 1 in the slot, 2, 3 in the staging area
+    float* __restrict__ exf = (fi < 2 ? slot : stage - 2 * EXF) + EXF * fi;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    // ---- pass 1: real radix-25 over x[t + 16 r] of frame 4 wv + fi, then the step twiddle --
     {
-      // exchange area of this lane's frame: frames 0, 1 in the slot, 2, 3 in the staging area
-      float* __restrict__ exf = (fi < 2 ? slot : stage - 2 * EXF) + EXF * fi;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-      // ---- pass 1: real radix-25 over x[t + 16 r] of frame 4 wv + fi, then the step twiddle --
-      {
-        float2 y[13];
-        float x[25];
-        // sample 160 fi + t + 16 r sits at 160 fi + t + 16 (r ^ e), e = 1 in the even rows
-        // fi + r / 10 of the span (the swizzle)
-        const int sel = (fi & 1) ^ 1;
-        const float* __restrict__ sp = stage + HOP * fi + role;
-        const float* __restrict__ spp = sp + 16 * sel;
-        const float* __restrict__ spm = sp - 16 * sel;
+      float2 y[13];
+      float x[25];
+      // sample 160 fi + t + 16 r sits at 160 fi + t + 16 (r ^ e), e = 1 in the even rows
+      // fi + r / 10 of the span (the swizzle)
+      const int sel = (fi & 1) ^ 1;
+      const float* __restrict__ sp = stage + HOP * fi + role;
+      const float* __restrict__ spp = sp + 16 * sel;
+      const float* __restrict__ spm = sp - 16 * sel;
+      if (MIA_DBG(p, 128)) {  // ablation: no sample reads
+#pragma unroll
+        for (int r = 0; r < 25; ++r) x[r] = wnd[r];
+      } else {
 #pragma unroll
         for (int r = 0; r < 25; ++r) {
           const int u = r ^ ((r / 10) & 1);
           x[r] = ((u & 1) ? spm : spp)[16 * u] * wnd[r];
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        if (MIA_DBG(p, 2)) {
-#pragma unroll
-          for (int k = 0; k < 13; ++k) y[k] = {x[2 * k], x[(2 * k + 1) % 25]};
-        } else {
-          rdft25(x, y);
-#pragma unroll
-          for (int k = 1; k < 13; ++k) y[k] = cmul(y[k], twd[k]);
-        }
-        float2* __restrict__ exw = reinterpret_cast<float2*>(exf + 26 * role);
-#pragma unroll
-        for (int c = 0; c < 13; ++c) exw[c] = y[c];
       }
-      STAMP(2)
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      if (MIA_DBG(p, 2)) {
+#pragma unroll
+        for (int k = 0; k < 13; ++k) y[k] = {x[2 * k], x[(2 * k + 1) % 25]};
+      } else {
+        rdft25(x, y);
+#pragma unroll
+        for (int k = 1; k < 13; ++k) y[k] = cmul(y[k], twd[k]);
+      }
+      float2* __restrict__ exw = reinterpret_cast<float2*>(exf + 26 * role);
+      if (!MIA_DBG(p, 64)) {  // (ablation bit 64: no exchange)
+#pragma unroll
+        for (int c = 0; c < 13; ++c) exw[c] = y[c];
+      } else {
+#pragma unroll
+        for (int c = 0; c < 13; ++c) asm volatile("" ::"v"(y[c].x), "v"(y[c].y));
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 
-      // ---- pass 2: radix-16 over the roles; v[k2] = X[k1 + 25 k2] ---------------------------
-      float pw[16];
-      {
-        float2 v[16];
-        const int k1r = role < 13 ? role : 12;
-        const float2* __restrict__ exr = reinterpret_cast<const float2*>(exf + 2 * k1r);
+    // ---- pass 2: radix-16 over the roles; v[k2] = X[k1 + 25 k2] ---------------------------
+    float pw[16];
+    {
+      float2 v[16];
+      const int k1r = role < 13 ? role : 12;
+      const float2* __restrict__ exr = reinterpret_cast<const float2*>(exf + 2 * k1r);
+      if (MIA_DBG(p, 64)) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = {wnd[q], wnd[q + 1]};
+      } else {
 #pragma unroll
         for (int q = 0; q < 16; ++q) v[q] = exr[13 * q];
-        if (!MIA_DBG(p, 2)) Dft<16>::run(v);
-#pragma unroll
-        for (int k2 = 0; k2 < 16; ++k2) pw[k2] = fmaf(v[k2].x, v[k2].x, v[k2].y * v[k2].y);
       }
-      // opaque: the exchange has been read back (the power values depend on it) before
-      // anything below is issued
+      if (!MIA_DBG(p, 2)) Dft<16>::run(v);
 #pragma unroll
-      for (int k2 = 0; k2 < 16; ++k2) asm volatile("" : "+v"(pw[k2]));
-      STAMP(3)
+      for (int k2 = 0; k2 < 16; ++k2) pw[k2] = fmaf(v[k2].x, v[k2].x, v[k2].y * v[k2].y);
+    }
+    // opaque: the exchange has been read back (the power values depend on it) before
+    // anything below is issued
+#pragma unroll
+    for (int k2 = 0; k2 < 16; ++k2) asm volatile("" : "+v"(pw[k2]));
 
-      // ---- the next tile's samples: the staging area is free from here on ------------------
-      if (more && !MIA_DBG(p, 16)) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        dma_wave_samples(g_y + (long long)cur_b * p.T, p.T,
-                         (long long)cur_tile * (FT * HOP) - p.pad + 4 * wv * HOP, p.pad_mode, lane,
-                         soff, stage, stage_bytes);
-      }
+    // ---- the next tile's samples: the staging area is free from here on ------------------
+    if (load_next && !MIA_DBG(p, 16)) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      dma_wave_samples(g_y + (long long)bn * p.T, p.T,
+                       (long long)tn * (FT * HOP) - p.pad + 4 * wv * HOP, p.pad_mode, lane, soff,
+                       stage, stage_bytes);
+    }
 
-      // ---- power columns of the wave's 4 frames: slot[4 * bin + fi] -------------------------
-      if (role < 13) {
-        float* __restrict__ pa = slot + 4 * role + fi;          // bins k1 + 25 k2, k2 = 0..7
-        float* __restrict__ pb = slot + 4 * (200 - role) + fi;  // bins 400 - (k1 + 25 k2), k2 = 8..15
+    // ---- power columns of the wave's 4 frames: slot[4 * bin + fi] -------------------------
+    if (role < 13 && !MIA_DBG(p, 256)) {  // (ablation bit 256: no power write)
+      float* __restrict__ pa = slot + 4 * role + fi;          // bins k1 + 25 k2, k2 = 0..7
+      float* __restrict__ pb = slot + 4 * (200 - role) + fi;  // bins 400 - (k1 + 25 k2), k2 = 8..15
 #pragma unroll
-        for (int k2 = 0; k2 < 8; ++k2) pa[4 * 25 * k2] = pw[k2];
-        pb[0] = pw[8];
-        if (role != 0) {  // butterfly 0 repeats bins 175, 150, ... it already wrote
+      for (int k2 = 0; k2 < 8; ++k2) pa[4 * 25 * k2] = pw[k2];
+      pb[0] = pw[8];
+      if (role != 0) {  // butterfly 0 repeats bins 175, 150, ... it already wrote
 #pragma unroll
-          for (int k2 = 9; k2 < 16; ++k2) pb[-4 * 25 * (k2 - 8)] = pw[k2];
-        }
+        for (int k2 = 9; k2 < 16; ++k2) pb[-4 * 25 * (k2 - 8)] = pw[k2];
       }
     }
-    STAMP(4)
-    // The power of this tile is complete, and every wave is done with the previous sweep.
-    // A bare barrier: the DMA stays in flight across it.
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    STAMP(5)
+  };
 
-    // ---- mel sweep + log epilogue (lane = frame) --------------------------------------------
-    {
-      const long long f0 = (long long)tile * FT;
-      const bool valid = f0 + lane < p.F;
-      const float* __restrict__ P = lds + (it & 1) * SL;
-      float* __restrict__ rowp = g_out + (((long long)b * p.n_mels + m0) * p.F + f0);
-      if (!MIA_DBG(p, 1)) {
-        const long long row0 = (long long)b * p.n_mels + m0;
-        const int has_prev = tile > 0 && idx > first;
-        const int flush = cur_tile == 0 || !more;  // last tile of the clip or of the run
-        const int nvalid = p.F - f0 < FT ? (int)(p.F - f0) : FT;
-        const int full = has_prev && !flush && nvalid == FT;
-        const unsigned mhi0 = mhi, mlo0 = mlo;
-        const float* __restrict__ pcol = P + (lane >> 2) * PW + (lane & 3);
-        char* __restrict__ rp = reinterpret_cast<char*>(rowp - 32);
-        const unsigned sg0 = 4u * (unsigned)((row0 * p.F) & 31), fm = 4u * (unsigned)(p.F & 31);
-        const unsigned f4 = 4u * (unsigned)p.F;
-        unsigned nhi, nlo;
-        if (full) {
-          SweepCtxDma<EPI, MAXR, true> c{p, pcol, rp, prev, 4u * (unsigned)lane, mhi, mlo, sg0, fm, 128u,
-                                         f4, 1, 0, FT, 0.0f, 0u};
-          compiled_sweep<BANK>(wv, c);
-          nhi = c.mhi;
-          nlo = c.mlo;
-        } else {
-          SweepCtxDma<EPI, MAXR, false> c{p, pcol, rp, prev, 4u * (unsigned)lane, mhi, mlo, sg0, fm, 128u,
-                                          f4, has_prev, flush, nvalid, 0.0f, 0u};
-          compiled_sweep<BANK>(wv, c);
-          nhi = c.mhi;
-          nlo = c.mlo;
-        }
-        // lanes past the clip's last frame swept padding: they do not count
-        mhi = valid ? nhi : mhi0;
-        mlo = valid ? nlo : mlo0;
+  // ---- mel sweep + log epilogue of tile ks = clip b, tile `tile` (lane = frame); ends with
+  // the wait that retires the loads in flight ----------------------------------------------
+  auto sweep = [&](int ks, int b, int tile, bool last_of_run) {
+    int tid = tid0;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63;
+    const long long f0 = (long long)tile * FT;
+    const bool valid = f0 + lane < p.F;
+    const bool last_of_clip = tile + 1 == p.tiles;
+    const float* __restrict__ P = lds + (ks & 1) * SL;
+    float* __restrict__ rowp = g_out + (((long long)b * p.n_mels + m0) * p.F + f0);
+    if (!MIA_DBG(p, 1)) {
+      const long long row0 = (long long)b * p.n_mels + m0;
+      const int has_prev = tile > 0 && ks > 0;
+      const int flush = last_of_clip || last_of_run;
+      const int nvalid = p.F - f0 < FT ? (int)(p.F - f0) : FT;
+      const int full = has_prev && !flush && nvalid == FT;
+      const unsigned mhi0 = mhi, mlo0 = mlo;
+      const float* __restrict__ pcol = P + (lane >> 2) * PW + (lane & 3);
+      char* __restrict__ rp = reinterpret_cast<char*>(rowp - 32);
+      const unsigned sg0 = 4u * (unsigned)((row0 * p.F) & 31), fm = 4u * (unsigned)(p.F & 31);
+      const unsigned f4 = 4u * (unsigned)p.F;
+      unsigned nhi, nlo;
+      if (full) {
+        SweepCtxDma<EPI, MAXR, true> c{p, pcol, rp, prev, 4u * (unsigned)lane, mhi, mlo, sg0, fm, 128u,
+                                       f4, 1, 0, FT, 0.0f, 0u};
+        compiled_sweep<BANK>(wv, c);
+        nhi = c.mhi;
+        nlo = c.mlo;
       } else {
-        wait_vmcnt<0>();  // no sweep, no stores: the DMA is the youngest operation
+        SweepCtxDma<EPI, MAXR, false> c{p, pcol, rp, prev, 4u * (unsigned)lane, mhi, mlo, sg0, fm, 128u,
+                                        f4, has_prev, flush, nvalid, 0.0f, 0u};
+        compiled_sweep<BANK>(wv, c);
+        nhi = c.mhi;
+        nlo = c.mlo;
       }
-      if (EPI != MIA_EPI_NONE && g_maxkey != nullptr && (cur_tile == 0 || !more)) {
-        unsigned rhi = mhi, rlo = mlo;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-          rhi = max(rhi, (unsigned)__shfl_xor((int)rhi, off));
-          rlo = min(rlo, (unsigned)__shfl_xor((int)rlo, off));
-        }
-        if (lane == 0 && rhi != 0u) {
-          float rmax = log_epilogue<EPI>(p, __builtin_bit_cast(float, rhi));
-          const float rmin = log_epilogue<EPI>(p, __builtin_bit_cast(float, rlo));
-          if (EPI == MIA_EPI_WHISPER) rmax = fmaf(rmax, 4.0f, -4.0f);
-          atomicMax(g_maxkey + b, float_to_key_nan(rmax));
-          atomicMin(g_minkey + b, float_to_key(rmin));
-        }
-        mhi = 0u;
-        mlo = 0x7F800000u;
-      }
+      // lanes past the clip's last frame swept padding: they do not count
+      mhi = valid ? nhi : mhi0;
+      mlo = valid ? nlo : mlo0;
+    } else {
+      wait_vmcnt<0>();  // no sweep, no stores: the DMA is the youngest operation
     }
-    STAMP(6)
-    STAMP(7)
-    STAMP_FLUSH
+    if (EPI != MIA_EPI_NONE && g_maxkey != nullptr && (last_of_clip || last_of_run)) {
+      unsigned rhi = mhi, rlo = mlo;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        rhi = max(rhi, (unsigned)__shfl_xor((int)rhi, off));
+        rlo = min(rlo, (unsigned)__shfl_xor((int)rlo, off));
+      }
+      if (lane == 0 && rhi != 0u) {
+        float rmax = log_epilogue<EPI>(p, __builtin_bit_cast(float, rhi));
+        const float rmin = log_epilogue<EPI>(p, __builtin_bit_cast(float, rlo));
+        if (EPI == MIA_EPI_WHISPER) rmax = fmaf(rmax, 4.0f, -4.0f);
+        atomicMax(g_maxkey + b, float_to_key_nan(rmax));
+        atomicMin(g_minkey + b, float_to_key(rmin));
+      }
+      mhi = 0u;
+      mlo = 0x7F800000u;
+    }
+  };
+
+  // ---- the first tile's samples --------------------------------------------------------------
+  dma_wave_samples(g_y + (long long)b1 * p.T, p.T,
+                   (long long)t1 * (FT * HOP) - p.pad + 4 * wv * HOP, p.pad_mode, tid0 & 63, soff,
+                   stage, stage_bytes);
+  wait_vmcnt<0>();
+
+  // ---- period k = -1 .. n - 1: the sweep of tile k (k >= 0) and the transform of tile k + 1
+  // (k + 1 < n), then ONE barrier ("P of tile k + 1 is complete, everyone is done sweeping tile
+  // k").  The two pieces do not depend on each other, and the waves of a SIMD take them in
+  // opposite orders (waves 4..7 and 12..15 transform first), so that one half's arithmetic
+  // runs beside the other half's LDS reads, rotations and stores instead of sixteen waves
+  // doing the same thing at once. ------------------------------------------------------------
+  const bool transform_first = W400D_STAGGER && (wv & 4) != 0;
+  for (int k = -1; k < n_run; ++k) {
+    const bool has_next = k + 1 < n_run;
+    if (transform_first && has_next) transform(k + 1, k + 2 < n_run, b2, t2);
+    if (k >= 0) {
+      __builtin_amdgcn_s_setprio(W400D_SWEEP_PRIO);
+      sweep(k, b0, t0, !has_next);
+      __builtin_amdgcn_s_setprio(0);
+    }
+    if (!transform_first && has_next) transform(k + 1, k + 2 < n_run, b2, t2);
+    // Every sweep ends with the wait for the loads in flight; the opening period has no
+    // sweep, and a transform-first wave reads tile 1's samples right after it.
+    if (k < 0) wait_vmcnt<0>();
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    b0 = b1, t0 = t1;
+    b1 = b2, t1 = t2;
+    advance(b2, t2);
   }
 }
 

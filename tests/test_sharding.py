@@ -70,6 +70,43 @@ def _worker(rank: int, world: int, port: int, n_clips: int, out_path: str):
         dist.destroy_process_group()
 
 
+def _gather_worker(rank: int, world: int, port: int, n_clips: int, chunk: int, out_path: str):
+    from mlx_audio_amd.sharding import FeatureGather
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        a, b = clip_shard(n_clips, rank, world)
+        g = FeatureGather(n_clips, (3, 7), torch.float32, "cpu", dst=0, chunk_clips=chunk)
+        for batch in range(3):  # the same gather object serves batch after batch
+            full_ref = (torch.arange(n_clips * 21, dtype=torch.float32).reshape(n_clips, 3, 7)
+                        + 1000.0 * batch)
+            work = g.start(full_ref[a:b].clone())
+            got = g.finish(work)
+            if rank == 0:
+                assert got.shape == (n_clips, 3, 7)
+                assert torch.equal(got, full_ref), batch
+            else:
+                assert got is None and g.full is None  # only the destination holds the tensor
+        with pytest.raises(ValueError):
+            g.start(torch.zeros((b - a + 1, 3, 7)))
+        if rank == 0:
+            open(out_path, "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_clips,chunk", [(2, 9, 2), (3, 10, 64), (3, 2, 1), (2, 1, 4)])
+def test_chunked_gather_to_rank0_only(tmp_path, world, n_clips, chunk):
+    """Ragged shards (the last rank may own fewer clips, or none), several chunks per peer,
+    and repeated use; no rank but 0 ever allocates the full tensor."""
+    out = tmp_path / "ok.txt"
+    mp.spawn(_gather_worker, args=(world, _free_port(), n_clips, chunk, str(out)), nprocs=world,
+             join=True)
+    assert out.read_text() == "ok"
+
+
 @pytest.mark.parametrize("n_clips", [4, 5])
 def test_two_ranks_shard_and_gather(tmp_path, n_clips):
     out = tmp_path / "ok.txt"
