@@ -192,7 +192,7 @@ def make_workload(name: str, clips: int, device, seed: int):
 
 
 KERNEL_OF = {
-    "whisper128": "logmel400_kernel (fused pad+frame+window+rFFT-400+128-mel+log10)",
+    "whisper128": "logmel400d_kernel (fused pad+frame+window+rFFT-400+128-mel+log10; LDS-DMA staging, compiled mel sweep, line-aligned stores)",
     "clap64": "fwd_kernel<1024, mel> (fused pad+frame+window+rFFT+mel+dB)",
     "mfcc40": "fwd_kernel<2048, mel> (fused rFFT+mel+dB) followed by dct2_mfma_kernel",
     "htdemucs": "fwd_kernel<4096> then istft_kernel<4096> (fused inverse FFT + overlap-add)",
@@ -222,11 +222,15 @@ def measured_traffic(workload: str, clips: int):
     return None if entry is None else entry.get("hbm_bytes_per_step")
 
 
-def cpu_baseline(budget_s: float = 12.0) -> dict:
+def cpu_baseline(budget_s: float = 8.0) -> dict:
     """The CPU oracle (NumPy float32 pocketfft + sgemm, the reference's op
     sequence) on the reference's CPU-runnable case: Whisper 80-mel log-mel of
-    16 synthetic 30 s clips, one call per clip, one thread."""
+    16 synthetic 30 s clips, one call per clip - on one thread, and with a
+    ThreadPoolExecutor over the clips (NumPy's FFT and BLAS release the GIL), BLAS
+    pinned to one thread per worker.  `value` is the threaded figure and `cores`
+    the workers it used; the single-thread figure rides along."""
     import numpy as np
+    from concurrent.futures import ThreadPoolExecutor
 
     import oracle.spectral as o
 
@@ -236,34 +240,98 @@ def cpu_baseline(budget_s: float = 12.0) -> dict:
         threadpool_limits = None
     rng = np.random.default_rng(42)
     x = rng.standard_normal((16, 480000), dtype=np.float32)
+    # the box's CPU share: OMP_NUM_THREADS is set to it there (os.cpu_count() shows the host)
+    share = int(os.environ.get("OMP_NUM_THREADS", "0") or 0) or (os.cpu_count() or 1)
+    workers = max(1, min(16, share))
 
-    def one_pass():
-        for i in range(16):
-            o.compute_log_mel_spectrogram(x[i], n_mels=80)
+    def one(i):
+        o.compute_log_mel_spectrogram(x[i], n_mels=80)
+
+    def timed(one_pass, budget):
+        one_pass()  # warm-up
+        times = []
+        t_end = time.perf_counter() + budget
+        while len(times) < 3 or (time.perf_counter() < t_end and len(times) < 20):
+            t0 = time.perf_counter()
+            one_pass()
+            times.append(time.perf_counter() - t0)
+        return times
 
     ctx = threadpool_limits(limits=1) if threadpool_limits else None
     if ctx is not None:
         ctx.__enter__()
     try:
-        one_pass()  # warm-up
-        times = []
-        t_end = time.perf_counter() + budget_s
-        while len(times) < 3 or (time.perf_counter() < t_end and len(times) < 20):
-            t0 = time.perf_counter()
-            one_pass()
-            times.append(time.perf_counter() - t0)
+        t1 = timed(lambda: [one(i) for i in range(16)], budget_s)
+        with ThreadPoolExecutor(max_workers=workers) as pool:
+            tn = timed(lambda: list(pool.map(one, range(16))), budget_s)
     finally:
         if ctx is not None:
             ctx.__exit__(None, None, None)
     hours = 16 * 30.0 / 3600.0
     return {
-        "value": hours / (sum(times) / len(times)),
+        "value": hours / (sum(tn) / len(tn)),
         "unit": "audio-hours/s",
-        "cores": 1,
+        "cores": workers,
         "kind": "port",
-        "sample": f"oracle (NumPy pocketfft f32) Whisper 80-mel log-mel, 16 x 30 s clips, "
-                  f"{len(times)} timed passes, host has {os.cpu_count()} logical CPUs",
+        "single_thread_value": hours / (sum(t1) / len(t1)),
+        "sample": f"oracle (NumPy pocketfft f32) Whisper 80-mel log-mel, 16 x 30 s clips, one "
+                  f"call per clip; {len(tn)} timed passes with {workers} worker threads over the "
+                  f"clips, {len(t1)} on one thread; host shows {os.cpu_count()} logical CPUs",
     }
+
+
+def _free_port() -> int:
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start N ranks of this same command
+    under torch.distributed.run (one process per GPU) and pass their output through.  Runs
+    before anything in this process has touched the GPU."""
+    import subprocess
+
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def launcher_selftest(args, world: int, rank: int) -> None:
+    """--workload none: no device work at all - forms the process group (gloo on CPUs, or
+    nccl), runs the timing harness around an empty step and prints the line, so that the
+    launcher path (`--gpus N` spawning N ranks) can be exercised without GPUs."""
+    import torch
+    import torch.distributed as dist
+
+    from mlx_audio_amd.sharding import max_over_ranks
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(args.backend)
+    n = dist.get_world_size() if world > 1 else 1
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pass
+    if world > 1:
+        dist.barrier()
+    elapsed = max_over_ranks(time.perf_counter() - t0, torch.device("cpu"))
+    if rank == 0:
+        print(json.dumps({"metric": "launcher self-test (no device work)", "value": None,
+                          "unit": None, "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": 1e3 * elapsed / max(args.steps, 1),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                          "dtype": None, "data": "none",
+                          "config": {"workload": "none", "backend": args.backend}}))
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def main() -> None:
@@ -275,8 +343,14 @@ def main() -> None:
     ap.add_argument("--clips", type=int, default=None, help="clips (rows) per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gather", action="store_true",
-                    help="also time one RCCL all-gather of the features to rank 0 (N > 1)")
+                    help="also time the run with every step's features collected on rank 0 "
+                         "(chunked sends on a side stream, overlapping the next step; N > 1)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend (gloo + --workload none: launcher self-test on CPUs)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus))
 
     import torch
 
@@ -285,6 +359,8 @@ def main() -> None:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.workload == "none":
+        return launcher_selftest(args, world, rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     device = torch.device("cuda", local_rank)
@@ -295,11 +371,12 @@ def main() -> None:
 
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
-    n_gpus = world if world > 1 else 1
+        dist.init_process_group(args.backend, device_id=device)
+    # the number of ranks the process group actually formed
+    n_gpus = dist.get_world_size() if dist is not None else 1
     if args.gpus != n_gpus and rank == 0:
-        print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: launch with "
-              "torch.distributed.run for N>1", file=sys.stderr)
+        print(f"[bench] --gpus {args.gpus} but the process group has {n_gpus} rank(s)",
+              file=sys.stderr)
 
     default_clips = {"whisper128": 1024, "clap64": 1024, "mfcc40": 1024, "htdemucs": 32,
                      "resample": 512, "resample_fft": 64, "features": 512, "contrast": 512, "onset": 4096, "griffinlim": 64, "spectral_gate": 64, "demucs_front": 16, "features_y": 512, "features_all": 512}
@@ -336,18 +413,34 @@ def main() -> None:
     barrier()
     elapsed = time.perf_counter() - t0
     dev_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
-    gather_ms = None
+    gather = None
     if args.gather and dist is not None and isinstance(out, torch.Tensor):
-        # Outside the headline number: the optional collection of the finished
-        # features on rank 0, one all-gather over xGMI.
-        from mlx_audio_amd.sharding import gather_features
+        # Outside the headline number: the same steps with every step's features collected
+        # on rank 0 - chunked point-to-point transfers on a side stream, so the transfer of
+        # step k runs beside the kernels of step k + 1 (two feature buffers alternate).
+        from mlx_audio_amd.sharding import FeatureGather
 
-        gather_features(out, n_gpus * clips)  # warm-up (communicator set-up)
+        g = FeatureGather(n_gpus * clips, out.shape[1:], out.dtype, device)
+        g.finish(g.start(out))  # warm-up (communicator set-up)
         barrier()
         tg = time.perf_counter()
-        gather_features(out, n_gpus * clips)
+        g.finish(g.start(out))
         barrier()
-        gather_ms = max_over_ranks(time.perf_counter() - tg, device) * 1e3
+        alone_ms = max_over_ranks(time.perf_counter() - tg, device) * 1e3
+        tg = time.perf_counter()
+        work = None
+        for k in range(args.steps):
+            nxt = step()
+            if work is not None:
+                g.finish(work)
+            work = g.start(nxt)
+        g.finish(work)
+        barrier()
+        with_ms = max_over_ranks(time.perf_counter() - tg, device) * 1e3 / args.steps
+        gather = {"gather_alone_ms": alone_ms, "ms_per_step_with_gather": with_ms,
+                  "value_with_gather": n_gpus * units / (with_ms * 1e-3),
+                  "note": "features of every step collected on rank 0 over xGMI, overlapped "
+                          "with the next step's kernels"}
     del out
     elapsed = max_over_ranks(elapsed, device)
 
@@ -385,8 +478,8 @@ def main() -> None:
                 "device_ms_per_step": dev_ms,
             },
         }
-        if gather_ms is not None:
-            line["gather_ms"] = gather_ms
+        if gather is not None:
+            line["gather"] = gather
         if n_gpus == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))

@@ -112,3 +112,23 @@ def test_two_ranks_shard_and_gather(tmp_path, n_clips):
     out = tmp_path / "ok.txt"
     mp.spawn(_worker, args=(2, _free_port(), n_clips, str(out)), nprocs=2, join=True)
     assert out.read_text() == "ok"
+
+
+def test_bench_launcher_spawns_the_ranks_it_is_asked_for():
+    """`python bench.py --gpus 2` with no launcher around it starts two ranks itself and
+    reports the world size the process group formed (gloo, no device work)."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps",
+                          "3", "--warmup", "1", "--workload", "none", "--backend", "gloo"],
+                         capture_output=True, text=True, env=env, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 3
