@@ -14,6 +14,8 @@ float32 FFT round-off (a few 1e-6 of the row's peak), not bit for bit.
 from __future__ import annotations
 
 import functools
+import threading
+from collections import OrderedDict
 import math
 
 import numpy as np
@@ -95,7 +97,35 @@ def resample(y, orig_sr: int, target_sr: int, res_type: str = "fft", fix: bool =
 
 
 _FFT_WORKSPACE_BYTES = 8 << 30  # rows are processed in chunks that keep the workspace below this
-_fft_tables_cache: dict = {}
+# (n_in, n_out, device) -> (tables, event recorded behind the kernels that fill them).  The
+# tables are built asynchronously on whichever stream was current at the first call; every
+# later user makes ITS stream wait for that event, so a consumer on another stream never
+# reads half-built tables.  Evicted entries stay alive as long as a caller holds them.
+_fft_tables_cache: "OrderedDict[tuple, tuple]" = OrderedDict()
+_fft_tables_lock = threading.Lock()
+_FFT_TABLES_MAX = 8
+
+
+def _fft_tables(lib, n_in: int, n_out: int, dev: torch.device, work: torch.Tensor):
+    key = (n_in, n_out, dev.index)
+    cur = torch.cuda.current_stream(dev)
+    with _fft_tables_lock:
+        hit = _fft_tables_cache.get(key)
+        if hit is not None:
+            _fft_tables_cache.move_to_end(key)
+            tables, ready = hit
+            cur.wait_event(ready)
+            return tables
+        tables = torch.empty(lib.mia_resample_fft_table_bytes(n_in, n_out), dtype=torch.uint8,
+                             device=dev)
+        _lib.check(lib.mia_resample_fft_tables(n_in, n_out, tables.data_ptr(), work.data_ptr(),
+                                               work.numel(), cur.cuda_stream))
+        ready = torch.cuda.Event()
+        ready.record(cur)
+        _fft_tables_cache[key] = (tables, ready)
+        while len(_fft_tables_cache) > _FFT_TABLES_MAX:
+            _fft_tables_cache.popitem(last=False)
+        return tables
 
 
 def _resample_fft(x: torch.Tensor, n_out: int, gain: float) -> torch.Tensor:
@@ -112,16 +142,7 @@ def _resample_fft(x: torch.Tensor, n_out: int, gain: float) -> torch.Tensor:
     with torch.cuda.device(dev):
         stream = stream_ptr(dev)
         work = torch.empty(chunk * per_row, dtype=torch.uint8, device=dev)
-        key = (n_in, n_out, dev.index)
-        tables = _fft_tables_cache.get(key)
-        if tables is None:
-            if len(_fft_tables_cache) >= 8:
-                _fft_tables_cache.clear()
-            tables = torch.empty(lib.mia_resample_fft_table_bytes(n_in, n_out), dtype=torch.uint8,
-                                 device=dev)
-            _lib.check(lib.mia_resample_fft_tables(n_in, n_out, tables.data_ptr(), work.data_ptr(),
-                                                   work.numel(), stream))
-            _fft_tables_cache[key] = tables
+        tables = _fft_tables(lib, n_in, n_out, dev, work)
         for r0 in range(0, rows, chunk):
             n = min(chunk, rows - r0)
             _lib.check(lib.mia_resample_fft(x[r0:r0 + n].data_ptr(), n, n_in, n_out, gain,

@@ -290,3 +290,33 @@ def test_c_abi_argument_checks(gpu):
         np.testing.assert_allclose(out[:n_out].cpu().numpy(), want, rtol=0, atol=1e-5)
     assert lib.mia_resample_fft(x9.data_ptr(), 1, 0, 4, 1.0, tab.data_ptr(), out.data_ptr(),
                                 work.data_ptr(), work.numel(), s) == _lib.MIA_ERR_INVALID
+
+
+def test_fourier_tables_built_on_one_stream_are_safe_on_another(gpu):
+    """The chirp-z tables are filled asynchronously on the stream of the first call; a second
+    call on another stream must wait for them (it used to read them half-built)."""
+    import mlx_audio_amd.primitives.resample as rs
+
+    rng = np.random.default_rng(31)
+    n, sr_in, sr_out = 30011, 30011, 11003  # a prime length: the chirp-z path, large tables
+    x = rng.standard_normal((3, n)).astype(np.float32)
+    want = orc.resample(x, sr_in, sr_out)
+    xd = torch.from_numpy(x).to(gpu)
+    with rs._fft_tables_lock:
+        rs._fft_tables_cache.clear()
+    a, b = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(a):
+        # a long kernel queue in front of the table build, so that it is still running when
+        # the other stream arrives
+        junk = torch.randn((1 << 26,), device=gpu)
+        for _ in range(20):
+            junk = junk * 1.0001 + 0.5
+        ya = resample(xd, sr_in, sr_out)
+    with torch.cuda.stream(b):
+        yb = resample(xd, sr_in, sr_out)  # cache hit on another stream
+    torch.cuda.synchronize()
+    peak = np.abs(want).max()
+    for got in (ya, yb):
+        assert np.abs(got.cpu().numpy() - want).max() <= 2e-6 * peak
+    assert torch.equal(ya, yb)
