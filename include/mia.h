@@ -115,6 +115,17 @@ int mia_fft_size_supported(int n_fft);
  * (stft.py:213-216).  Every value is multiplied by `scale`. */
 int mia_stft(const mia_plan* plan, const float* y, int64_t B, int64_t T,
              float scale, void* out, void* stream);
+/* The same for every plan.  An n_fft without a compiled kernel (mia_fft_size_supported() == 0)
+ * is served by an any-length engine - mx.fft.rfft takes any length, primitives/stft.py:130 -
+ * that materialises the frames in `workspace` (mia_stft_workspace_bytes() bytes; 0 for the
+ * compiled sizes, where this is mia_stft) and transforms them by mixed-radix passes (2-3-5-7
+ * smooth lengths) or a chirp-z convolution (all others, odd and prime lengths included).
+ * mia_istft, mia_melspectrogram and mia_mfcc serve such plans through the workspaces they
+ * already take; mia_stft, mia_irfft_frames, mia_spectral_stats and mia_melspectrogram_static
+ * reject them. */
+size_t mia_stft_workspace_bytes(const mia_plan* plan, int64_t B, int64_t T);
+int mia_stft_ws(const mia_plan* plan, const float* y, int64_t B, int64_t T, float scale,
+                void* out, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Inverse real FFT of every frame.  Replaces mx.fft.irfft at
  * primitives/stft.py:295.  spec is addressed as

@@ -62,6 +62,9 @@ SIGNATURES = {
     "mia_plan_num_frames": (c_int64, [c_void_p, c_int64]),
     "mia_fft_size_supported": (c_int, [c_int]),
     "mia_stft": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_float, c_void_p, c_void_p]),
+    "mia_stft_workspace_bytes": (c_size_t, [c_void_p, c_int64, c_int64]),
+    "mia_stft_ws": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_float, c_void_p, c_void_p,
+                            c_size_t, c_void_p]),
     "mia_irfft_frames": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64,
                                  c_void_p, c_void_p]),
     "mia_overlap_add": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_int64,

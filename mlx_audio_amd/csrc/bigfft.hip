@@ -395,6 +395,288 @@ static RfLayout rf_layout(long long n_in, long long n_out) {
   return l;
 }
 
+
+// ---------------------------------------------------------------------------
+// Any-length frames: the plan of an n_fft that has no compiled LDS kernel.  Frames are
+// materialised as complex rows in a caller workspace and transformed by the whole-row engine
+// above - mixed-radix passes when n_fft is 2-3-5-7-smooth, else a chirp-z convolution over a
+// power-of-two length - in chunks of rows that bound the workspace.  A fallback that accepts
+// what the reference accepts (any n_fft, odd ones included); the compiled plans are the fast
+// path.
+// ---------------------------------------------------------------------------
+constexpr size_t kGenericChunkBytes = 256u << 20;  // per buffer
+
+static bool smooth2357(long long n) {
+  int r[32];
+  return n == 1 || plan_radices(n, r) != 0;
+}
+long long generic_row_len(int n_fft) {  // complex elements per row in the workspace buffers
+  return smooth2357(n_fft) ? (long long)n_fft : (1LL << conv_log2(n_fft));
+}
+long long generic_chunk_rows(int n_fft, long long rows) {
+  const long long per = (long long)(kGenericChunkBytes / (sizeof(float2) * (size_t)generic_row_len(n_fft)));
+  const long long c = per < 1 ? 1 : per;
+  return rows < c ? (rows < 1 ? 1 : rows) : c;
+}
+size_t generic_fft_bytes(int n_fft, long long rows) {  // the two row buffers
+  return 2 * sizeof(float2) * (size_t)generic_chunk_rows(n_fft, rows) * (size_t)generic_row_len(n_fft);
+}
+
+// Chirp and filter spectrum of the chirp-z path (nothing to build for smooth lengths).
+int generic_build_tables(int n_fft, float2** d_chirp, float2** d_bspec) {
+  *d_chirp = nullptr;
+  *d_bspec = nullptr;
+  if (smooth2357(n_fft)) return MIA_OK;
+  const int p = conv_log2(n_fft);
+  const long long L = 1LL << p;
+  float2 *w0 = nullptr, *w1 = nullptr;
+  MIA_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(d_chirp), sizeof(float2) * (size_t)n_fft));
+  MIA_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(d_bspec), sizeof(float2) * (size_t)L));
+  MIA_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&w0), sizeof(float2) * (size_t)L));
+  MIA_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&w1), sizeof(float2) * (size_t)L));
+  hipLaunchKernelGGL(chirp_kernel, dim3(blocks_for(n_fft)), dim3(256), 0, 0, (long long)n_fft, *d_chirp);
+  hipLaunchKernelGGL(chirp_filter_kernel, dim3(blocks_for(L)), dim3(256), 0, 0, *d_chirp,
+                     (long long)n_fft, L, w0);
+  float2* res = nullptr;
+  int rc = fft_pow2(w0, w1, p, 1, 0, &res);
+  if (rc == MIA_OK) {
+    rc = hipMemcpy(*d_bspec, res, sizeof(float2) * (size_t)L, hipMemcpyDeviceToDevice) == hipSuccess
+             ? MIA_OK : MIA_ERR_HIP;
+  }
+  (void)hipDeviceSynchronize();
+  (void)hipFree(w0);
+  (void)hipFree(w1);
+  return rc;
+}
+
+// a[row, m] = window[m] * y[clip, frame * hop - pad + m] (times conj(chirp[m]) on the chirp-z
+// path) for m < N, zero up to L; rows are frames row0 .. row0 + nrows - 1 of the (B, F) grid.
+__global__ __launch_bounds__(256) void generic_frames_kernel(
+    const float* __restrict__ y, long long T, long long F, int N, int hop, int pad, int pad_mode,
+    const float* __restrict__ win, const float2* __restrict__ chirp, long long L, long long row0,
+    long long nrows, float2* __restrict__ a) {
+  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= nrows * L) return;
+  const long long row = g / L, m = g - row * L;
+  float2 v = {0.0f, 0.0f};
+  if (m < N) {
+    const long long fr = row0 + row, b = fr / F, f = fr - b * F;
+    const float xv = fetch_sample(y + b * T, T, f * hop - pad + m, pad_mode) * win[m];
+    if (chirp != nullptr) {
+      const float2 c = chirp[m];
+      v = {xv * c.x, -xv * c.y};
+    } else {
+      v = {xv, 0.0f};
+    }
+  }
+  a[g] = v;
+}
+
+// Bin k of row `row` from the transformed buffer: r[k] itself on the smooth path,
+// conj(chirp[k] * r[k]) / L on the chirp-z path.
+__device__ __forceinline__ float2 generic_bin(const float2* __restrict__ r, const float2* __restrict__ chirp,
+                                              long long L, float inv_L, long long row, long long k) {
+  const float2 v = r[row * L + k];
+  if (chirp == nullptr) return v;
+  const float2 q = cmulf(chirp[k], v);
+  return {q.x * inv_L, -q.y * inv_L};
+}
+
+__global__ __launch_bounds__(256) void generic_store_bins_kernel(
+    const float2* __restrict__ r, const float2* __restrict__ chirp, long long L, float inv_L, int bins,
+    long long row0, long long nrows, float scale, float2* __restrict__ out) {
+  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= nrows * bins) return;
+  const long long row = g / bins, k = g - row * bins;
+  const float2 X = generic_bin(r, chirp, L, inv_L, row, k);
+  out[(row0 + row) * bins + k] = {X.x * scale, X.y * scale};
+}
+
+// Mel projection + epilogue of the rows of one chunk: one thread per (filter, frame), frames
+// fastest (coalesced stores); the per-clip extremes go straight to the keys.
+__global__ __launch_bounds__(256) void generic_mel_kernel(
+    const float2* __restrict__ r, const float2* __restrict__ chirp, long long L, float inv_L,
+    long long F, long long row0, long long nrows, FwdParams p) {
+  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= nrows * p.n_mels) return;
+  const int m = (int)(g / nrows);
+  const long long row = g - (long long)m * nrows;
+  const long long fr = row0 + row, b = fr / F, f = fr - b * F;
+  const int lo = p.row_lo[m], len = p.row_len[m];
+  const float* __restrict__ w = p.wts + p.row_off[m];
+  float acc = 0.0f;
+  for (int j = 0; j < len; ++j) {
+    const float2 X = generic_bin(r, chirp, L, inv_L, row, lo + j);
+    float pw = X.x * X.x + X.y * X.y;
+    if (p.power_mode == 1) pw = sqrtf(pw);
+    else if (p.power_mode == 2) pw = powf(sqrtf(pw), p.power);
+    acc = fmaf(w[j], pw, acc);
+  }
+  float outv = acc;
+  if (p.epi == MIA_EPI_WHISPER) {
+    const float yv = acc <= 1e-10f ? -10.0f : __log10f(acc);
+    outv = (yv + 4.0f) * 0.25f;
+    if (p.clip_max_key != nullptr) {
+      atomicMax(p.clip_max_key + b, float_to_key_nan(yv));
+      atomicMin(p.clip_min_key + b, float_to_key(outv));
+    }
+  } else if (p.epi == MIA_EPI_DB) {
+    outv = acc <= p.amin ? p.db_floor : p.coef * __log10f(acc * p.inv_ref);
+    if (p.clip_max_key != nullptr) {
+      atomicMax(p.clip_max_key + b, float_to_key_nan(outv));
+      atomicMin(p.clip_min_key + b, float_to_key(outv));
+    }
+  }
+  p.mout[(b * p.n_mels + m) * F + f] = outv;
+}
+
+// Forward transform of the frames of chunk [row0, row0 + nrows); *res = the buffer holding it.
+static int generic_forward_chunk(const mia_plan* plan, const FwdParams& p, long long row0, long long nrows,
+                                 float2* bufA, float2* bufB, hipStream_t s, const float2** res) {
+  const int N = plan->n_fft;
+  const bool cz = plan->d_chirp != nullptr;
+  const long long L = generic_row_len(N);
+  hipLaunchKernelGGL(generic_frames_kernel, dim3(blocks_for(nrows * L)), dim3(256), 0, s, p.y, p.T, p.F,
+                     N, p.hop, p.pad, p.pad_mode, p.win, cz ? plan->d_chirp : nullptr, L, row0, nrows,
+                     bufA);
+  MIA_CHECK_HIP(hipGetLastError());
+  if (!cz) {
+    if (N == 1) {
+      *res = bufA;
+      return MIA_OK;
+    }
+    return fft_any(bufA, bufB, bufA, L, nrows, s, res);  // in = its second buffer: allowed
+  }
+  const int lg = conv_log2(N);
+  float2* r0 = nullptr;
+  int rc = fft_pow2(bufA, bufB, lg, nrows, s, &r0);
+  if (rc != MIA_OK) return rc;
+  float2* other = r0 == bufA ? bufB : bufA;
+  hipLaunchKernelGGL(spectrum_product_kernel, dim3(blocks_for(nrows << lg)), dim3(256), 0, s, r0,
+                     plan->d_bspec, lg, nrows);
+  MIA_CHECK_HIP(hipGetLastError());
+  float2* r1 = nullptr;
+  rc = fft_pow2(r0, other, lg, nrows, s, &r1);
+  if (rc != MIA_OK) return rc;
+  *res = r1;
+  return MIA_OK;
+}
+
+int launch_forward_generic(const mia_plan* plan, const FwdParams& p, int mode, void* workspace,
+                           size_t workspace_bytes, hipStream_t s) {
+  const long long rows = p.B * p.F;
+  if (rows <= 0) return MIA_OK;
+  const int N = plan->n_fft, bins = N / 2 + 1;
+  MIA_REQUIRE(workspace != nullptr && workspace_bytes >= generic_fft_bytes(N, rows),
+              "workspace too small for n_fft=%d: %zu bytes, need %zu", N, workspace_bytes,
+              generic_fft_bytes(N, rows));
+  const long long L = generic_row_len(N), chunk = generic_chunk_rows(N, rows);
+  float2* bufA = reinterpret_cast<float2*>(workspace);
+  float2* bufB = bufA + chunk * L;
+  const bool cz = plan->d_chirp != nullptr;
+  const float inv_L = 1.0f / (float)L;
+  for (long long row0 = 0; row0 < rows; row0 += chunk) {
+    const long long n = rows - row0 < chunk ? rows - row0 : chunk;
+    const float2* res = nullptr;
+    const int rc = generic_forward_chunk(plan, p, row0, n, bufA, bufB, s, &res);
+    if (rc != MIA_OK) return rc;
+    if (mode == 0) {
+      hipLaunchKernelGGL(generic_store_bins_kernel, dim3(blocks_for(n * bins)), dim3(256), 0, s, res,
+                         cz ? plan->d_chirp : nullptr, L, inv_L, bins, row0, n, p.scale, p.cout);
+    } else {
+      hipLaunchKernelGGL(generic_mel_kernel, dim3(blocks_for(n * p.n_mels)), dim3(256), 0, s, res,
+                         cz ? plan->d_chirp : nullptr, L, inv_L, p.F, row0, n, p);
+    }
+    MIA_CHECK_HIP(hipGetLastError());
+  }
+  return MIA_OK;
+}
+
+// Inverse: conj of the Hermitian extension of the bins of frames [row0, row0 + nrows)
+// (imaginary parts of DC and of an even length's Nyquist bin dropped, as a complex-to-real
+// transform ignores them), chirp-premultiplied on the chirp-z path, zero up to L.
+__global__ __launch_bounds__(256) void generic_spectrum_rows_kernel(
+    const float2* __restrict__ spec, long long sb, long long sk, long long sf, long long F, int N,
+    const float2* __restrict__ chirp, long long L, long long row0, long long nrows,
+    float2* __restrict__ a) {
+  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= nrows * L) return;
+  const long long row = g / L, k = g - row * L;
+  float2 v = {0.0f, 0.0f};
+  if (k < N) {
+    const long long fr = row0 + row, b = fr / F, f = fr - b * F;
+    const bool neg = 2 * k > N;
+    const long long kk = neg ? N - k : k;
+    float2 X = spec[b * sb + kk * sk + f * sf];
+    if (kk == 0 || 2 * kk == N) X.y = 0.0f;
+    // full spectrum Z[k] = neg ? conj(X) : X; the transform input is conj(Z)
+    const float2 Zc = {X.x, neg ? X.y : -X.y};
+    if (chirp != nullptr) {
+      const float2 c = chirp[k];
+      v = cmulf(Zc, float2{c.x, -c.y});
+    } else {
+      v = Zc;
+    }
+  }
+  a[g] = v;
+}
+
+__global__ __launch_bounds__(256) void generic_store_frames_kernel(
+    const float2* __restrict__ r, const float2* __restrict__ chirp, long long L, float inv_L, int N,
+    long long row0, long long nrows, float* __restrict__ frames) {
+  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= nrows * N) return;
+  const long long row = g / N, n = g - row * N;
+  // x[n] = Re(conj(DFT(conj Z))[n]) / N = Re(DFT(conj Z)[n]) / N
+  const float2 X = generic_bin(r, chirp, L, inv_L, row, n);
+  frames[(row0 + row) * N + n] = X.x / (float)N;
+}
+
+int launch_inverse_generic(const mia_plan* plan, const InvParams& p, void* workspace,
+                           size_t workspace_bytes, hipStream_t s) {
+  const long long rows = p.B * p.F;
+  if (rows <= 0) return MIA_OK;
+  const int N = plan->n_fft;
+  MIA_REQUIRE(workspace != nullptr && workspace_bytes >= generic_fft_bytes(N, rows),
+              "workspace too small for n_fft=%d: %zu bytes, need %zu", N, workspace_bytes,
+              generic_fft_bytes(N, rows));
+  const long long L = generic_row_len(N), chunk = generic_chunk_rows(N, rows);
+  float2* bufA = reinterpret_cast<float2*>(workspace);
+  float2* bufB = bufA + chunk * L;
+  const bool cz = plan->d_chirp != nullptr;
+  const float inv_L = 1.0f / (float)L;
+  for (long long row0 = 0; row0 < rows; row0 += chunk) {
+    const long long n = rows - row0 < chunk ? rows - row0 : chunk;
+    hipLaunchKernelGGL(generic_spectrum_rows_kernel, dim3(blocks_for(n * L)), dim3(256), 0, s, p.spec,
+                       p.sb, p.sk, p.sf, p.F, N, cz ? plan->d_chirp : nullptr, L, row0, n, bufA);
+    MIA_CHECK_HIP(hipGetLastError());
+    const float2* res = bufA;
+    if (!cz) {
+      if (N > 1) {
+        const int rc = fft_any(bufA, bufB, bufA, L, n, s, &res);
+        if (rc != MIA_OK) return rc;
+      }
+    } else {
+      const int lg = conv_log2(N);
+      float2* r0 = nullptr;
+      int rc = fft_pow2(bufA, bufB, lg, n, s, &r0);
+      if (rc != MIA_OK) return rc;
+      float2* other = r0 == bufA ? bufB : bufA;
+      hipLaunchKernelGGL(spectrum_product_kernel, dim3(blocks_for(n << lg)), dim3(256), 0, s, r0,
+                         plan->d_bspec, lg, n);
+      MIA_CHECK_HIP(hipGetLastError());
+      float2* r1 = nullptr;
+      rc = fft_pow2(r0, other, lg, n, s, &r1);
+      if (rc != MIA_OK) return rc;
+      res = r1;
+    }
+    hipLaunchKernelGGL(generic_store_frames_kernel, dim3(blocks_for(n * N)), dim3(256), 0, s, res,
+                       cz ? plan->d_chirp : nullptr, L, inv_L, N, row0, n, p.frames);
+    MIA_CHECK_HIP(hipGetLastError());
+  }
+  return MIA_OK;
+}
+
 }  // namespace mia
 
 extern "C" {

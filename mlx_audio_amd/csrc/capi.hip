@@ -221,6 +221,8 @@ static void plan_free(mia_plan* p) {
   (void)hipFree(p->d_tw16);
   (void)hipFree(p->d_sweep_meta);
   (void)hipFree(p->d_sweep_w);
+  (void)hipFree(p->d_chirp);
+  (void)hipFree(p->d_bspec);
   delete p;
 }
 
@@ -400,17 +402,13 @@ extern "C" {
 int mia_plan_create(const mia_plan_desc* d, mia_plan** out) {
   MIA_REQUIRE(d != nullptr && out != nullptr, "null argument");
   *out = nullptr;
-  MIA_REQUIRE(d->n_fft > 0 && d->n_fft % 2 == 0, "n_fft must be positive and even, got %d",
-              d->n_fft);
+  MIA_REQUIRE(d->n_fft > 0, "n_fft must be positive, got %d", d->n_fft);
+  MIA_REQUIRE(d->n_fft <= (1 << 24), "n_fft=%d is beyond the supported 2^24", d->n_fft);
   MIA_REQUIRE(d->hop_length > 0, "hop_length must be positive, got %d", d->hop_length);
   MIA_REQUIRE(d->window != nullptr, "window is required");
   MIA_REQUIRE(d->pad_mode >= 0 && d->pad_mode <= 2, "bad pad_mode %d", d->pad_mode);
-  if (!fft_size_supported(d->n_fft)) {
-    set_error("n_fft=%d has no compiled FFT plan (supported: 256, 400, 512, 800, 1024, 2048, "
-              "4096)", d->n_fft);
-    return MIA_ERR_UNSUPPORTED;
-  }
   mia_plan* p = new mia_plan();
+  p->generic = fft_size_supported(d->n_fft) ? 0 : 1;  // no compiled kernel: the any-length engine
   int rc = MIA_OK;
   auto fail = [&](int code) {
     plan_free(p);
@@ -434,6 +432,7 @@ int mia_plan_create(const mia_plan_desc* d, mia_plan** out) {
   p->pad_mode = d->pad_mode;
   p->power = d->power;
   const int N = d->n_fft, bins = N / 2 + 1;
+  if (p->generic && (rc = generic_build_tables(N, &p->d_chirp, &p->d_bspec)) != MIA_OK) return fail(rc);
   {
     std::vector<float> w(d->window, d->window + N);
     if ((rc = upload(&p->d_window, w)) != MIA_OK) return fail(rc);
@@ -544,6 +543,8 @@ int64_t mia_plan_num_frames(const mia_plan* plan, int64_t T) {
 
 }  // extern "C"
 
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
 static int fill_fwd(const mia_plan* plan, const float* y, int64_t B, int64_t T, FwdParams& p) {
   MIA_REQUIRE(plan != nullptr, "null plan");
   MIA_REQUIRE(y != nullptr || B == 0, "null input");
@@ -578,9 +579,33 @@ int mia_stft(const mia_plan* plan, const float* y, int64_t B, int64_t T, float s
   int rc = fill_fwd(plan, y, B, T, p);
   if (rc != MIA_OK) return rc;
   MIA_REQUIRE(out != nullptr || B == 0, "null output");
+  if (plan->generic) {
+    set_error("n_fft=%d has no compiled kernel: call mia_stft_ws with mia_stft_workspace_bytes() "
+              "bytes of workspace", plan->n_fft);
+    return MIA_ERR_INVALID;
+  }
   p.scale = scale;
   p.cout = reinterpret_cast<float2*>(out);
   return launch_forward(plan, p, 0, (hipStream_t)stream);
+}
+
+size_t mia_stft_workspace_bytes(const mia_plan* plan, int64_t B, int64_t T) {
+  if (!plan || !plan->generic || B <= 0) return 0;
+  const int64_t F = mia_plan_num_frames(plan, T);
+  return F <= 0 ? 0 : generic_fft_bytes(plan->n_fft, B * F);
+}
+
+int mia_stft_ws(const mia_plan* plan, const float* y, int64_t B, int64_t T, float scale, void* out,
+                void* workspace, size_t workspace_bytes, void* stream) {
+  MIA_REQUIRE(plan != nullptr, "null plan");
+  if (!plan->generic) return mia_stft(plan, y, B, T, scale, out, stream);
+  FwdParams p;
+  int rc = fill_fwd(plan, y, B, T, p);
+  if (rc != MIA_OK) return rc;
+  MIA_REQUIRE(out != nullptr || B == 0, "null output");
+  p.scale = scale;
+  p.cout = reinterpret_cast<float2*>(out);
+  return launch_forward_generic(plan, p, 0, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 int mia_irfft_frames(const mia_plan* plan, const void* spec, int64_t B, int64_t F,
@@ -589,6 +614,11 @@ int mia_irfft_frames(const mia_plan* plan, const void* spec, int64_t B, int64_t 
   MIA_REQUIRE(plan != nullptr, "null plan");
   MIA_REQUIRE(B >= 0 && F >= 0, "negative shape");
   MIA_REQUIRE((spec && frames) || B == 0 || F == 0, "null buffer");
+  if (plan->generic) {
+    set_error("n_fft=%d has no compiled kernel: use mia_istft (it takes the workspace the "
+              "any-length engine needs)", plan->n_fft);
+    return MIA_ERR_UNSUPPORTED;
+  }
   InvParams p{};
   p.spec = reinterpret_cast<const float2*>(spec);
   p.B = B;
@@ -614,6 +644,10 @@ int mia_overlap_add(const float* frames, const float* window, int64_t B, int64_t
 
 size_t mia_istft_workspace_bytes(const mia_plan* plan, int64_t B, int64_t F) {
   if (!plan || B <= 0 || F <= 0) return 0;
+  if (plan->generic) {  // frames + the any-length engine's row buffers
+    return align256(sizeof(float) * (size_t)B * (size_t)F * (size_t)plan->n_fft) +
+           generic_fft_bytes(plan->n_fft, B * F);
+  }
   if (mia::istft_fused_supported(plan->n_fft, plan->hop)) return 0;  // overlap kept in LDS
   return sizeof(float) * (size_t)B * (size_t)F * (size_t)plan->n_fft;
 }
@@ -622,6 +656,29 @@ int mia_istft(const mia_plan* plan, const void* spec, int64_t B, int64_t F, int6
               int64_t stride_bin, int64_t stride_frame, int64_t out_len, float scale, float* out,
               void* workspace, size_t workspace_bytes, void* stream) {
   MIA_REQUIRE(plan != nullptr, "null plan");
+  if (plan->generic) {
+    MIA_REQUIRE(B >= 0 && F >= 0 && out_len >= 0, "negative shape");
+    MIA_REQUIRE((spec && out) || B == 0 || F == 0 || out_len == 0, "null buffer");
+    if (B == 0 || out_len == 0) return MIA_OK;
+    MIA_REQUIRE(workspace_bytes >= mia_istft_workspace_bytes(plan, B, F),
+                "workspace too small: %zu < %zu", workspace_bytes,
+                mia_istft_workspace_bytes(plan, B, F));
+    float* frames = reinterpret_cast<float*>(workspace);
+    const size_t fbytes = align256(sizeof(float) * (size_t)B * (size_t)F * (size_t)plan->n_fft);
+    InvParams p{};
+    p.spec = reinterpret_cast<const float2*>(spec);
+    p.B = B;
+    p.F = F;
+    p.sb = stride_b;
+    p.sk = stride_bin;
+    p.sf = stride_frame;
+    p.frames = frames;
+    int rc = launch_inverse_generic(plan, p, reinterpret_cast<char*>(workspace) + fbytes,
+                                    workspace_bytes - fbytes, (hipStream_t)stream);
+    if (rc != MIA_OK) return rc;
+    return mia_overlap_add(frames, plan->d_window, B, F, plan->n_fft, plan->hop, out_len, scale,
+                           out, stream);
+  }
   if (mia::istft_fused_supported(plan->n_fft, plan->hop)) {
     MIA_REQUIRE(B >= 0 && F >= 0 && out_len >= 0, "negative shape");
     MIA_REQUIRE((spec && out) || B == 0 || F == 0 || out_len == 0, "null buffer");
@@ -658,18 +715,19 @@ int mia_istft(const mia_plan* plan, const void* spec, int64_t B, int64_t F, int6
 
 }  // extern "C"
 
-static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
-
 extern "C" size_t mia_mel_workspace_bytes(const mia_plan* plan, int64_t B, int64_t T) {
   if (!plan || B <= 0) return 0;
   const int64_t F = mia_plan_num_frames(plan, T);
   if (F <= 0) return 0;
-  return 2 * align256(sizeof(int) * (size_t)(B + 1));
+  const size_t keys = 2 * align256(sizeof(int) * (size_t)(B + 1));
+  return plan->generic ? keys + generic_fft_bytes(plan->n_fft, B * F) : keys;
 }
 
 // The n_fft = 400 kernel when the plan has its tables (and a clip's output fits the
 // kernel's 32-bit offsets), else the generic one.
-static int forward_mel_dispatch(const mia_plan* plan, const FwdParams& p, hipStream_t s) {
+static int forward_mel_dispatch(const mia_plan* plan, const FwdParams& p, hipStream_t s,
+                                void* fft_ws = nullptr, size_t fft_ws_bytes = 0) {
+  if (plan->generic) return launch_forward_generic(plan, p, 1, fft_ws, fft_ws_bytes, s);
   if (plan->d_sweep_meta != nullptr && p.n_mels * p.F < (1LL << 30)) {
     W400Tables tb{plan->d_win16, plan->d_tw16, plan->d_sweep_meta, plan->d_sweep_w,
                   plan->w400_bank, plan->opt_table_sweep, plan->opt_vgpr_staging, plan->cus};
@@ -719,7 +777,13 @@ static int mel_forward(const mia_plan* plan, const float* y, int64_t B, int64_t 
 #ifdef MIA_DEBUG_HOOKS
   { const char* e = getenv("MIA_DBG"); p.dbg = e ? atoi(e) : 0; }  // profiling builds only
 #endif
-  rc = forward_mel_dispatch(plan, p, s);
+  const size_t keys_bytes = 2 * align256(sizeof(int) * (size_t)(B + 1));
+  if (plan->generic && B > 0) {
+    MIA_REQUIRE(workspace != nullptr && workspace_bytes >= mia_mel_workspace_bytes(plan, B, T),
+                "workspace too small (any-length plans need mia_mel_workspace_bytes() bytes)");
+  }
+  rc = forward_mel_dispatch(plan, p, s, reinterpret_cast<char*>(workspace) + keys_bytes,
+                            workspace_bytes > keys_bytes ? workspace_bytes - keys_bytes : 0);
   if (rc != MIA_OK) return rc;
 #ifdef MIA_DEBUG_HOOKS
   if (p.dbg != 0) return rc;  // ablation runs time the main kernel alone (their data is garbage)
@@ -745,6 +809,8 @@ int mia_melspectrogram_static(const mia_plan* plan, const float* y, int64_t B, i
                               int epilogue, float ref, float amin, float coef, float top_db,
                               int per_clip, float* out, void* stream) {
   MIA_REQUIRE(plan != nullptr, "null plan");
+  MIA_REQUIRE(!plan->generic, "n_fft=%d has no compiled kernel: its any-length plan needs the "
+              "workspace of mia_melspectrogram", plan->n_fft);
   MIA_REQUIRE(B <= MIA_STATIC_MAX_CLIPS,
               "mia_melspectrogram_static holds clamp keys for at most %d clips, got %lld "
               "(use mia_melspectrogram with a workspace)", MIA_STATIC_MAX_CLIPS, (long long)B);
@@ -825,7 +891,11 @@ int mia_mfcc(const mia_plan* plan, const float* y, int64_t B, int64_t T, float t
   if ((rc = launch_init_keys(keys, min_keys, B + 1, s)) != MIA_OK) return rc;
   p.clip_max_key = keys;
   p.clip_min_key = min_keys;
-  rc = forward_mel_dispatch(plan, p, s);
+  {
+    const size_t keys_bytes = 2 * align256(sizeof(int) * (size_t)(B + 1));
+    rc = forward_mel_dispatch(plan, p, s, reinterpret_cast<char*>(workspace) + keys_bytes,
+                              melws > keys_bytes ? melws - keys_bytes : 0);
+  }
   if (rc != MIA_OK) return rc;
   if (clamp && !per_clip) {
     // global maximum: fold keys[0..B) into keys[B]

@@ -98,6 +98,10 @@ struct mia_plan {
   float* d_sweep_w = nullptr;    // [16][W400_MEL_MAXC][32] per-wave sweep program (see logmel400.hip)
   int w400_bank = 0;             // 80 / 128 when the filterbank is that compiled-in Whisper bank
   int cus = 256;                 // compute units of the device (sizes the persistent grids)
+  // any-length plan (n_fft without a compiled LDS kernel): whole-row engine of bigfft.hip
+  int generic = 0;
+  float2* d_chirp = nullptr;     // chirp-z path only: exp(i pi n^2 / n_fft)
+  float2* d_bspec = nullptr;     // ... and the spectrum of the convolution kernel
   int opt_table_sweep = 0;       // mia_plan_set_option("w400_table_sweep"): ablation / test knob
   int opt_vgpr_staging = 0;      // mia_plan_set_option("w400_vgpr_staging"): ablation / test knob
 };
@@ -174,6 +178,14 @@ int launch_init_keys(int* max_keys, int* min_keys, long long n, hipStream_t s);
 int launch_logmel400(const FwdParams& p, const W400Tables& tb, hipStream_t s);
 int w400_compiled_bank(const float* basis, int n_mels, int bins);
 bool fft_size_supported(int n_fft);
+long long generic_row_len(int n_fft);
+long long generic_chunk_rows(int n_fft, long long rows);
+size_t generic_fft_bytes(int n_fft, long long rows);
+int generic_build_tables(int n_fft, float2** d_chirp, float2** d_bspec);
+int launch_forward_generic(const mia_plan* plan, const FwdParams& p, int mode, void* workspace,
+                           size_t workspace_bytes, hipStream_t s);
+int launch_inverse_generic(const mia_plan* plan, const InvParams& p, void* workspace,
+                           size_t workspace_bytes, hipStream_t s);
 int forward_tile_frames(int n_fft, int mode);
 
 }  // namespace mia

@@ -40,9 +40,15 @@ def _stft_raw(y2d: torch.Tensor, n_fft, hop_length, win_length, window, center, 
     B, T = y2d.shape
     F = plan.num_frames(T)
     out = torch.empty((B, F, n_fft // 2 + 1), dtype=torch.complex64, device=y2d.device)
+    lib = _lib.lib()
+    # 0 bytes for the compiled FFT sizes; other lengths run on the any-length engine, which
+    # materialises its frames in a workspace
+    ws_bytes = lib.mia_stft_workspace_bytes(plan.handle, B, T)
+    ws = torch.empty((max(ws_bytes, 1),), dtype=torch.uint8, device=y2d.device)
     with torch.cuda.device(y2d.device):
-        _lib.check(_lib.lib().mia_stft(plan.handle, y2d.data_ptr(), B, T, float(scale),
-                                       out.data_ptr(), stream_ptr(y2d.device)))
+        _lib.check(lib.mia_stft_ws(plan.handle, y2d.data_ptr(), B, T, float(scale),
+                                   out.data_ptr(), ws.data_ptr(), ws_bytes,
+                                   stream_ptr(y2d.device)))
     return out
 
 

@@ -295,8 +295,10 @@ def test_c_abi_argument_checks(gpu):
 def test_fourier_tables_built_on_one_stream_are_safe_on_another(gpu):
     """The chirp-z tables are filled asynchronously on the stream of the first call; a second
     call on another stream must wait for them (it used to read them half-built)."""
-    import mlx_audio_amd.primitives.resample as rs
+    import importlib
 
+    rs = importlib.import_module("mlx_audio_amd.primitives.resample")  # (the package re-exports
+    # a function of the same name)
     rng = np.random.default_rng(31)
     n, sr_in, sr_out = 30011, 30011, 11003  # a prime length: the chirp-z path, large tables
     x = rng.standard_normal((3, n)).astype(np.float32)

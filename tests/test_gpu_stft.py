@@ -104,8 +104,7 @@ def test_stft_errors(gpu):
         stft(y, n_fft=512, pad_mode="wrap")
     with pytest.raises(ValueError, match="must be >= frame_length"):
         stft(torch.zeros(100, device=gpu), n_fft=512, center=False)
-    with pytest.raises(NotImplementedError):
-        stft(y, n_fft=300)
+    assert stft(y, n_fft=300).shape == (151, 1 + 1000 // 75)  # no compiled kernel: any-length engine
     # 10 ms at 44.1 kHz is shorter than n_fft but centre padding makes it long enough
     assert stft(torch.zeros(441, device=gpu), n_fft=512).shape == (257, 4)
 
@@ -264,3 +263,78 @@ def test_magnitude_and_phase_of_the_stft_view_skip_the_copy(gpu):
             b = fn(C.contiguous())
             assert a.shape == C.shape and a.is_contiguous()
             assert torch.equal(a, b)
+
+
+# ---- n_fft without a compiled kernel: the any-length engine (mixed radix / chirp-z) ----------
+ANY_N_FFT = [300, 441, 1000, 1536, 8192, 97, 1023, 6]
+
+
+@pytest.mark.parametrize("n_fft", ANY_N_FFT)
+@pytest.mark.parametrize("pad_mode", ["constant", "reflect"])
+def test_stft_any_length_matches_oracle(gpu, n_fft, pad_mode):
+    import oracle.spectral as o
+    from mlx_audio_amd.primitives import stft
+
+    rng = np.random.default_rng(n_fft)
+    hop = max(1, n_fft // 4 + (1 if n_fft % 3 == 0 else 0))
+    y = rng.standard_normal((3, 5 * n_fft + 37)).astype(np.float32)
+    got = stft(torch.from_numpy(y).to(gpu), n_fft=n_fft, hop_length=hop, pad_mode=pad_mode).cpu().numpy()
+    want = o.stft(y, n_fft=n_fft, hop_length=hop, pad_mode=pad_mode, dtype=np.float64)
+    assert got.shape == want.shape == (3, n_fft // 2 + 1, 1 + (y.shape[1] + 2 * (n_fft // 2) - n_fft) // hop)
+    assert np.abs(got - want).max() <= 4e-6 * np.abs(want).max()
+
+
+@pytest.mark.parametrize("n_fft", [300, 441, 1000, 1536, 8192, 97])
+def test_istft_any_length_round_trip_and_oracle(gpu, n_fft):
+    import oracle.spectral as o
+    from mlx_audio_amd.primitives import istft, stft
+
+    rng = np.random.default_rng(1000 + n_fft)
+    hop = n_fft // 4
+    T = 6 * n_fft + 11
+    y = rng.standard_normal((2, T)).astype(np.float32)
+    S = stft(torch.from_numpy(y).to(gpu), n_fft=n_fft, hop_length=hop)
+    rec = istft(S, hop_length=hop, n_fft=n_fft, length=T).cpu().numpy()
+    snr = 10 * np.log10((y.astype(np.float64) ** 2).sum() / ((y - rec).astype(np.float64) ** 2).sum())
+    assert snr >= 100.0, snr
+    # the inverse alone, on a spectrum that is not the transform of a signal
+    Z = (rng.standard_normal((2, n_fft // 2 + 1, 9)) + 1j * rng.standard_normal((2, n_fft // 2 + 1, 9)))
+    Z = Z.astype(np.complex64)
+    got = istft(torch.from_numpy(Z).to(gpu), hop_length=hop, n_fft=n_fft).cpu().numpy()
+    want = o.istft(Z, hop_length=hop, n_fft=n_fft, dtype=np.float64)
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() <= 4e-6 * np.abs(want).max()
+
+
+@pytest.mark.parametrize("n_fft,n_mels", [(300, 20), (441, 40), (1000, 64), (1536, 80)])
+def test_mel_and_mfcc_any_length(gpu, n_fft, n_mels):
+    import oracle.spectral as o
+    from mlx_audio_amd.primitives import melspectrogram, mfcc
+
+    rng = np.random.default_rng(n_fft + n_mels)
+    y = rng.standard_normal((2, 16000)).astype(np.float32)
+    yd = torch.from_numpy(y).to(gpu)
+    got = melspectrogram(yd, sr=16000, n_fft=n_fft, hop_length=n_fft // 3, n_mels=n_mels).cpu().numpy()
+    want = np.stack([o.melspectrogram(y[b], sr=16000, n_fft=n_fft, hop_length=n_fft // 3, n_mels=n_mels)
+                     for b in range(2)])
+    np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-5 * want.max())
+    gm = mfcc(yd, sr=16000, n_mfcc=13, n_fft=n_fft, hop_length=n_fft // 3, n_mels=n_mels,
+              per_clip=True).cpu().numpy()
+    wm = np.stack([o.mfcc(y[b], sr=16000, n_mfcc=13, n_fft=n_fft, hop_length=n_fft // 3, n_mels=n_mels)
+                   for b in range(2)])
+    np.testing.assert_allclose(gm, wm, rtol=1e-5, atol=2e-3)
+
+
+def test_any_length_plans_reject_the_entry_points_without_workspace(gpu):
+    from mlx_audio_amd import _lib
+    from mlx_audio_amd._runtime import get_plan
+    from mlx_audio_amd.primitives.windows import padded_window_np
+
+    lib = _lib.lib()
+    assert lib.mia_fft_size_supported(300) == 0 and lib.mia_fft_size_supported(400) == 1
+    plan = get_plan(gpu, 300, 75, True, "constant", padded_window_np("hann", 300, 300))
+    y = torch.zeros((1, 1000), device=gpu)
+    out = torch.empty((1, plan.num_frames(1000), 151), dtype=torch.complex64, device=gpu)
+    assert lib.mia_stft_workspace_bytes(plan.handle, 1, 1000) > 0
+    rc = lib.mia_stft(plan.handle, y.data_ptr(), 1, 1000, 1.0, out.data_ptr(), None)
+    assert rc == _lib.MIA_ERR_INVALID and b"mia_stft_ws" in lib.mia_last_error()
