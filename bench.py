@@ -10,8 +10,8 @@ data-path collective — and the aggregate is reported (weak scaling).
 Workloads (config.workload):
   whisper128  [default] 1024 x 30 s @16 kHz -> (1024, 128, 3001) log-mel
   clap64      1024 x 10 s @48 kHz -> (1024, 1001, 64) dB mel
-  mfcc40      1024 x 30 s @16 kHz, n_fft 2048 / hop 512 / 128 mels -> 40 MFCC
-  htdemucs    16 stereo x 60 s @44.1 kHz STFT+iSTFT round trip, n_fft 4096 / hop 1024
+  mfcc40      4096 x 30 s @16 kHz (the per-GPU pool of a stream), n_fft 2048 / hop 512 / 128 mels -> 40 MFCC
+  htdemucs    64 stereo x 180 s @44.1 kHz STFT+iSTFT round trip, n_fft 4096 / hop 1024
   resample    512 x 30 s @44.1 kHz -> 16 kHz, polyphase (up 160 / down 441)
   resample_fft 64 x 30 s @44.1 kHz -> 16 kHz, Fourier method (the reference's default)
   features    centroid + bandwidth + roll-off + flatness of a (512, 1025, 938) spectrogram
@@ -73,7 +73,7 @@ def make_workload(name: str, clips: int, device, seed: int):
                 f"MFCC-40, {clips} x 30 s clips @16 kHz, n_fft 2048 hop 512, 128 mels",
                 "MFCC-40 audio-hours/sec")
     if name == "htdemucs":
-        T = 44100 * 60
+        T = 44100 * 180
         rows = clips  # channel rows (stereo tracks * 2)
         y = 0.1 * torch.randn((rows, T), generator=gen, device=device, dtype=torch.float32)
         frames = 1 + T // 1024
@@ -83,8 +83,8 @@ def make_workload(name: str, clips: int, device, seed: int):
             S = stft(y, n_fft=4096, hop_length=1024, pad_mode="reflect")
             return istft(S, hop_length=1024, length=T)
 
-        return (step, rows / 2 * 60.0 / 3600.0, abytes,
-                f"HTDemucs STFT+iSTFT round trip, {rows // 2} stereo x 60 s @44.1 kHz, "
+        return (step, rows / 2 * 180.0 / 3600.0, abytes,
+                f"HTDemucs STFT+iSTFT round trip, {rows // 2} stereo x 180 s @44.1 kHz, "
                 "n_fft 4096 hop 1024", "STFT round-trip track-hours/sec (n_fft 4096)")
     if name == "resample":
         T = 44100 * 30
@@ -378,7 +378,7 @@ def main() -> None:
         print(f"[bench] --gpus {args.gpus} but the process group has {n_gpus} rank(s)",
               file=sys.stderr)
 
-    default_clips = {"whisper128": 1024, "clap64": 1024, "mfcc40": 1024, "htdemucs": 32,
+    default_clips = {"whisper128": 1024, "clap64": 1024, "mfcc40": 4096, "htdemucs": 128,
                      "resample": 512, "resample_fft": 64, "features": 512, "contrast": 512, "onset": 4096, "griffinlim": 64, "spectral_gate": 64, "demucs_front": 16, "features_y": 512, "features_all": 512}
     clips = args.clips or default_clips.get(args.workload, 1024)
     step, units, abytes, desc, metric = make_workload(args.workload, clips, device, 1234 + rank)

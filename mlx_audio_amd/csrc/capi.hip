@@ -19,6 +19,7 @@ void set_error(const char* fmt, ...) {
   g_last_error = buf;
 }
 
+constexpr int64_t kMaxGridRows = 65535;  // gridDim.y of the row-per-block-row launches
 int launch_overlap_add(const float*, const float*, long long, long long, int, int, long long,
                        float, float*, hipStream_t);
 int launch_pad(const float*, long long, long long, long long, int, float*, hipStream_t);
@@ -636,10 +637,15 @@ int mia_overlap_add(const float* frames, const float* window, int64_t B, int64_t
   MIA_REQUIRE(n_fft > 0, "n_fft must be positive, got %d", n_fft);
   MIA_REQUIRE(hop > 0, "hop_length must be positive, got %d", hop);
   MIA_REQUIRE(B >= 0 && F >= 0 && out_len >= 0, "negative shape");
-  MIA_REQUIRE(B <= 65535, "batch %lld exceeds 65535", (long long)B);
   MIA_REQUIRE((frames && window && out) || B == 0 || out_len == 0, "null buffer");
-  return launch_overlap_add(frames, window, B, F, n_fft, hop, out_len, scale, out,
-                            (hipStream_t)stream);
+  for (int64_t b0 = 0; b0 < B; b0 += kMaxGridRows) {  // a launch takes at most 65535 rows
+    const int64_t nb = B - b0 < kMaxGridRows ? B - b0 : kMaxGridRows;
+    const int rc = launch_overlap_add(frames + (size_t)b0 * F * n_fft, window, nb, F, n_fft, hop,
+                                      out_len, scale, out + (size_t)b0 * out_len,
+                                      (hipStream_t)stream);
+    if (rc != MIA_OK) return rc;
+  }
+  return MIA_OK;
 }
 
 size_t mia_istft_workspace_bytes(const mia_plan* plan, int64_t B, int64_t F) {
@@ -856,10 +862,27 @@ size_t mia_mfcc_workspace_bytes(const mia_plan* plan, int64_t B, int64_t T) {
 int mia_mfcc(const mia_plan* plan, const float* y, int64_t B, int64_t T, float top_db,
              int per_clip, float* out, void* workspace, size_t workspace_bytes, void* stream) {
   MIA_REQUIRE(plan != nullptr && plan->n_mfcc > 0, "plan has no DCT stage");
-  MIA_REQUIRE(B >= 0 && B <= 65535, "batch %lld out of range", (long long)B);
+  MIA_REQUIRE(B >= 0, "batch %lld out of range", (long long)B);
   if (B == 0) return MIA_OK;
   MIA_REQUIRE(workspace != nullptr && workspace_bytes >= mia_mfcc_workspace_bytes(plan, B, T),
               "workspace too small");
+  if (B > kMaxGridRows) {
+    // Clips are independent when the maximum is per clip: the batch goes through in pieces
+    // that fit one launch, each in the same workspace (sized for the whole batch).
+    MIA_REQUIRE(per_clip || top_db < 0.0f,
+                "a batch-wide top_db maximum over %lld clips needs per_clip != 0 (at most 65535 "
+                "clips share one maximum)", (long long)B);
+    const int64_t Fq = mia_plan_num_frames(plan, T);
+    if (Fq < 0) return (int)Fq;
+    for (int64_t b0 = 0; b0 < B; b0 += kMaxGridRows) {
+      const int64_t nb = B - b0 < kMaxGridRows ? B - b0 : kMaxGridRows;
+      const int rc = mia_mfcc(plan, y + (size_t)b0 * T, nb, T, top_db, per_clip,
+                              out + (size_t)b0 * plan->n_mfcc * Fq, workspace, workspace_bytes,
+                              stream);
+      if (rc != MIA_OK) return rc;
+    }
+    return MIA_OK;
+  }
   hipStream_t s = (hipStream_t)stream;
   const size_t melws = align256(mia_mel_workspace_bytes(plan, B, T));
   float* sdb = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + melws);
@@ -914,13 +937,18 @@ int mia_pad_signal(const float* x, int64_t B, int64_t T, int64_t pad, int mode, 
   MIA_REQUIRE(B >= 0 && T >= 0, "negative shape");
   MIA_REQUIRE(pad >= 0, "pad_length must be non-negative, got %lld", (long long)pad);
   MIA_REQUIRE(mode >= 0 && mode <= 2, "Unknown pad_mode code %d", mode);
-  MIA_REQUIRE(B <= 65535, "batch %lld exceeds 65535", (long long)B);
   if (mode == MIA_PAD_REFLECT && pad > 0) {
     MIA_REQUIRE(pad <= T - 1, "reflect padding of %lld needs a signal longer than %lld samples",
                 (long long)pad, (long long)pad);
   }
   if (mode == MIA_PAD_EDGE && pad > 0) MIA_REQUIRE(T >= 1, "empty signal");
-  return launch_pad(x, B, T, pad, mode, out, (hipStream_t)stream);
+  for (int64_t b0 = 0; b0 < B; b0 += kMaxGridRows) {
+    const int64_t nb = B - b0 < kMaxGridRows ? B - b0 : kMaxGridRows;
+    const int rc = launch_pad(x + (size_t)b0 * T, nb, T, pad, mode, out + (size_t)b0 * (T + 2 * pad),
+                              (hipStream_t)stream);
+    if (rc != MIA_OK) return rc;
+  }
+  return MIA_OK;
 }
 
 int mia_frame_signal(const float* x, int64_t B, int64_t T, int frame_length, int hop, float* out,
@@ -930,26 +958,45 @@ int mia_frame_signal(const float* x, int64_t B, int64_t T, int frame_length, int
   MIA_REQUIRE(T >= frame_length,
               "Signal length (%lld) must be >= frame_length (%d). Consider padding the signal.",
               (long long)T, frame_length);
-  MIA_REQUIRE(B >= 0 && B <= 65535, "batch %lld out of range", (long long)B);
+  MIA_REQUIRE(B >= 0, "batch %lld out of range", (long long)B);
   const int64_t F = 1 + (T - frame_length) / hop;
-  return launch_frame(x, B, T, F, frame_length, hop, out, (hipStream_t)stream);
+  for (int64_t b0 = 0; b0 < B; b0 += kMaxGridRows) {
+    const int64_t nb = B - b0 < kMaxGridRows ? B - b0 : kMaxGridRows;
+    const int rc = launch_frame(x + (size_t)b0 * T, nb, T, F, frame_length, hop,
+                                out + (size_t)b0 * F * frame_length, (hipStream_t)stream);
+    if (rc != MIA_OK) return rc;
+  }
+  return MIA_OK;
 }
 
 int mia_to_db(const float* x, int64_t B, int64_t n, float ref, float amin, float coef,
               float top_db, int per_clip, float* out, void* workspace, void* stream) {
   MIA_REQUIRE(B >= 0 && n >= 0, "negative shape");
-  MIA_REQUIRE(B <= 65535, "batch %lld exceeds 65535", (long long)B);
   MIA_REQUIRE(top_db < 0.0f || workspace != nullptr, "workspace required for top_db");
-  return launch_to_db(x, B, n, ref, amin, coef, top_db, per_clip, out,
-                      reinterpret_cast<int*>(workspace), (hipStream_t)stream);
+  MIA_REQUIRE(B <= kMaxGridRows || per_clip || top_db < 0.0f,
+              "one top_db maximum over %lld rows needs per_clip != 0 (at most 65535 rows share a "
+              "maximum)", (long long)B);
+  for (int64_t b0 = 0; b0 < B; b0 += kMaxGridRows) {  // rows are independent from here on
+    const int64_t nb = B - b0 < kMaxGridRows ? B - b0 : kMaxGridRows;
+    const int rc = launch_to_db(x + (size_t)b0 * n, nb, n, ref, amin, coef, top_db, per_clip,
+                                out + (size_t)b0 * n, reinterpret_cast<int*>(workspace),
+                                (hipStream_t)stream);
+    if (rc != MIA_OK) return rc;
+  }
+  return MIA_OK;
 }
 
 int mia_dct2(const float* x, int64_t outer, int n_in, int64_t inner, const float* basis,
              int n_out, float* out, void* stream) {
   MIA_REQUIRE(outer >= 0 && inner >= 0 && n_in > 0 && n_out > 0, "bad shape");
-  MIA_REQUIRE(outer <= 65535, "outer %lld exceeds 65535", (long long)outer);
-  return launch_dct2(x, outer, n_in, inner, basis, n_out, out, nullptr, 0, 0.0f,
-                     (hipStream_t)stream);
+  for (int64_t o0 = 0; o0 < outer; o0 += kMaxGridRows) {
+    const int64_t no = outer - o0 < kMaxGridRows ? outer - o0 : kMaxGridRows;
+    const int rc = launch_dct2(x + (size_t)o0 * n_in * inner, no, n_in, inner, basis, n_out,
+                               out + (size_t)o0 * n_out * inner, nullptr, 0, 0.0f,
+                               (hipStream_t)stream);
+    if (rc != MIA_OK) return rc;
+  }
+  return MIA_OK;
 }
 
 int mia_magnitude(const void* z, int64_t n, float* out, void* stream) {

@@ -286,7 +286,18 @@ int mia_gate_mask_box(const float* mag, const float* thr, int64_t rows, int bins
               "the threshold must have one row per signal row, or a single row of per-bin values");
   if (rows == 0 || frames == 0) return MIA_OK;
   MIA_REQUIRE(mag && thr && out, "null pointer");
-  MIA_REQUIRE(rows <= 65535 && bins <= 65535 && frames <= 0x7fffffffLL, "shape too large for one launch");
+  MIA_REQUIRE(bins <= 65535 && frames <= 0x7fffffffLL, "shape too large for one launch");
+  if (rows > 65535) {  // a launch takes 65535 rows: the rest follows in further launches
+    for (int64_t r0 = 0; r0 < rows; r0 += 65535) {
+      const int64_t nr = rows - r0 < 65535 ? rows - r0 : 65535;
+      const float* thr_r = rows_thr == rows ? thr + (size_t)r0 * (per_bin ? bins : bins * frames) : thr;
+      const int rc = mia_gate_mask_box(mag + (size_t)r0 * bins * frames, thr_r, nr, bins, frames,
+                                       per_bin, rows_thr == rows ? nr : 1, gain, keep, p, size_freq,
+                                       out + (size_t)r0 * bins * frames, stream);
+      if (rc != MIA_OK) return rc;
+    }
+    return MIA_OK;
+  }
   const dim3 grid((unsigned)((frames + 255) / 256), (unsigned)bins, (unsigned)rows);
   hipLaunchKernelGGL(gate_mask_box_kernel, grid, dim3(256), 0, (hipStream_t)stream, mag, thr,
                      (unsigned)rows, (unsigned)bins, (unsigned)frames, per_bin, (unsigned)rows_thr,
@@ -301,7 +312,17 @@ int mia_gate_apply(const float* mag, const float* mask, const float* phase, int6
   MIA_REQUIRE(rows >= 0 && bins >= 0 && frames >= 0 && size_time >= 1, "negative shape or size");
   if (rows == 0 || bins == 0 || frames == 0) return MIA_OK;
   MIA_REQUIRE(mag && mask && phase && out, "null pointer");
-  MIA_REQUIRE(rows <= 65535 && (bins + 31) / 32 <= 65535, "at most 65535 rows per call");
+  MIA_REQUIRE((bins + 31) / 32 <= 65535, "too many bins for one launch");
+  if (rows > 65535) {  // a launch takes 65535 rows: the rest follows in further launches
+    for (int64_t r0 = 0; r0 < rows; r0 += 65535) {
+      const int64_t nr = rows - r0 < 65535 ? rows - r0 : 65535;
+      const size_t off = (size_t)r0 * bins * frames;
+      const int rc = mia_gate_apply(mag + off, mask + off, phase + off, nr, bins, frames, keep, p,
+                                    size_time, (float2*)out + off, stream);
+      if (rc != MIA_OK) return rc;
+    }
+    return MIA_OK;
+  }
   const dim3 grid((unsigned)((frames + 31) / 32), (unsigned)((bins + 31) / 32), (unsigned)rows);
   hipLaunchKernelGGL(gate_apply_kernel, grid, dim3(32, 8), 0, (hipStream_t)stream, mag, mask, phase,
                      (long long)bins, (long long)frames, keep, p, size_time, (float2*)out);

@@ -81,7 +81,16 @@ int mia_spectrum_part(const void* z, int64_t rows, int64_t frames, int64_t bins,
   MIA_REQUIRE(op == 0 || op == 1, "op must be 0 (magnitude) or 1 (phase)");
   if (rows == 0 || frames == 0 || bins == 0) return MIA_OK;
   MIA_REQUIRE(z && out, "null pointer");
-  MIA_REQUIRE(rows <= 65535 && (bins + 31) / 32 <= 65535, "at most 65535 rows per call");
+  MIA_REQUIRE((bins + 31) / 32 <= 65535, "too many bins for one launch");
+  if (rows > 65535) {  // a launch takes 65535 rows: the rest follows in further launches
+    for (int64_t r0 = 0; r0 < rows; r0 += 65535) {
+      const int64_t nr = rows - r0 < 65535 ? rows - r0 : 65535;
+      const size_t off = (size_t)r0 * frames * bins;
+      const int rc = mia_spectrum_part((const float2*)z + off, nr, frames, bins, op, out + off, stream);
+      if (rc != MIA_OK) return rc;
+    }
+    return MIA_OK;
+  }
   const dim3 grid((unsigned)((frames + 31) / 32), (unsigned)((bins + 31) / 32), (unsigned)rows);
   hipLaunchKernelGGL(spectrum_part_kernel, grid, dim3(32, 8), 0, (hipStream_t)stream,
                      (const float2*)z, (long long)frames, (long long)bins, op, out);

@@ -134,9 +134,17 @@ int mia_normalize_rows(const float* x, int64_t rows, int64_t n, float eps, float
                        void* sums, void* stream) {
   using namespace mia;
   MIA_REQUIRE(rows >= 0 && n >= 1, "rows and n must be >= 0 and 1");
-  MIA_REQUIRE(rows <= 65535, "at most 65535 rows per call");
   if (rows == 0) return MIA_OK;
   MIA_REQUIRE(x && out && stats && sums, "null pointer");
+  if (rows > 65535) {  // a launch takes 65535 rows: the rest follows in further launches
+    for (int64_t r0 = 0; r0 < rows; r0 += 65535) {
+      const int64_t nr = rows - r0 < 65535 ? rows - r0 : 65535;
+      const int rc = mia_normalize_rows(x + (size_t)r0 * n, nr, n, eps, out + (size_t)r0 * n,
+                                        stats + 2 * (size_t)r0, (double*)sums + 2 * (size_t)r0, stream);
+      if (rc != MIA_OK) return rc;
+    }
+    return MIA_OK;
+  }
   hipStream_t s = (hipStream_t)stream;
   MIA_CHECK_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 2 * (size_t)rows, s));
   // about 2048 workgroups in all: enough to fill the device, few enough that the two atomics
@@ -158,9 +166,21 @@ int mia_normalize_cac(const void* spec, int64_t batch, int channels, int64_t bin
   using namespace mia;
   MIA_REQUIRE(batch >= 0 && channels >= 1 && bins >= 1 && frames >= 1,
               "batch, channels, bins, frames must be >= 0, 1, 1, 1");
-  MIA_REQUIRE(batch * channels <= 65535, "at most 65535 (batch x channel) planes per call");
+  MIA_REQUIRE(channels <= 65535, "at most 65535 channels");
   if (batch == 0) return MIA_OK;
   MIA_REQUIRE(spec && out && stats && sums, "null pointer");
+  if (batch * channels > 65535) {  // a launch takes 65535 planes: batch items go through in groups
+    const int64_t per = 65535 / channels;
+    for (int64_t b0 = 0; b0 < batch; b0 += per) {
+      const int64_t nb = batch - b0 < per ? batch - b0 : per;
+      const int rc = mia_normalize_cac((const float2*)spec + (size_t)b0 * stride_b, nb, channels, bins,
+                                       frames, stride_b, stride_c, stride_f, stride_t, eps,
+                                       out + (size_t)b0 * 2 * channels * bins * frames,
+                                       stats + 2 * (size_t)b0, (double*)sums + 2 * (size_t)b0, stream);
+      if (rc != MIA_OK) return rc;
+    }
+    return MIA_OK;
+  }
   hipStream_t s = (hipStream_t)stream;
   MIA_CHECK_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 2 * (size_t)batch, s));
   long long chunks = frames;
