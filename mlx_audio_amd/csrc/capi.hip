@@ -220,6 +220,7 @@ static void plan_free(mia_plan* p) {
   (void)hipFree(p->d_dct);
   (void)hipFree(p->d_win16);
   (void)hipFree(p->d_tw16);
+  (void)hipFree(p->d_winp);
   (void)hipFree(p->d_sweep_meta);
   (void)hipFree(p->d_sweep_w);
   (void)hipFree(p->d_chirp);
@@ -391,6 +392,11 @@ static int build_w400_tables(mia_plan* p, const float* window, const float* basi
     }
   }
   int rc;
+  std::vector<float> winp((size_t)kWaves * 32, 0.0f);  // the prime-factor split's sample order
+  for (int n1 = 0; n1 < kWaves; ++n1) {
+    for (int n2 = 0; n2 < 25; ++n2) winp[(size_t)n1 * 32 + n2] = window[(25 * n1 + 16 * n2) % 400];
+  }
+  if ((rc = upload(&p->d_winp, winp)) != MIA_OK) return rc;
   if ((rc = upload(&p->d_win16, win16)) != MIA_OK) return rc;
   if ((rc = upload(&p->d_tw16, tw16)) != MIA_OK) return rc;
   if ((rc = upload(&p->d_sweep_meta, meta)) != MIA_OK) return rc;
@@ -735,7 +741,7 @@ static int forward_mel_dispatch(const mia_plan* plan, const FwdParams& p, hipStr
                                 void* fft_ws = nullptr, size_t fft_ws_bytes = 0) {
   if (plan->generic) return launch_forward_generic(plan, p, 1, fft_ws, fft_ws_bytes, s);
   if (plan->d_sweep_meta != nullptr && p.n_mels * p.F < (1LL << 30)) {
-    W400Tables tb{plan->d_win16, plan->d_tw16, plan->d_sweep_meta, plan->d_sweep_w,
+    W400Tables tb{plan->d_win16, plan->d_tw16, plan->d_winp, plan->d_sweep_meta, plan->d_sweep_w,
                   plan->w400_bank, plan->opt_table_sweep, plan->opt_vgpr_staging, plan->cus};
     return launch_logmel400(p, tb, s);
   }

@@ -308,4 +308,49 @@ __device__ __forceinline__ void rdft25(const float (&x)[25], float2 (&X)[13]) {
   X[3] = cconj(B2[4]);
 }
 
+// The same for windowed input: bins 0..12 of the DFT of x[n] * w[n], with the window
+// multiply folded into the first butterflies (x1 w1 +/- x4 w4 as one product and two fused
+// multiply-adds): 10 instructions fewer than 25 products in front of rdft25.
+__device__ __forceinline__ void rdft5w(float x0, float w0, float x1, float w1, float x2, float w2,
+                                       float x3, float w3, float x4, float w4, float& X0, float2& X1,
+                                       float2& X2) {
+  constexpr float c1 = 0.30901699437494742410f;   // cos(2pi/5)
+  constexpr float c2 = -0.80901699437494742410f;  // cos(4pi/5)
+  constexpr float s1 = 0.95105651629515357212f;   // sin(2pi/5)
+  constexpr float s2 = 0.58778525229247312917f;   // sin(4pi/5)
+  const float a0 = x0 * w0, t4 = x4 * w4, t3 = x3 * w3;
+  const float p = fmaf(x1, w1, t4), u = fmaf(x1, w1, -t4);
+  const float q = fmaf(x2, w2, t3), v = fmaf(x2, w2, -t3);
+  X0 = a0 + p + q;
+  X1 = {a0 + c1 * p + c2 * q, -(s1 * u + s2 * v)};
+  X2 = {a0 + c2 * p + c1 * q, s1 * v - s2 * u};
+}
+__device__ __forceinline__ void rdft25w(const float (&x)[25], const float (&w)[25], float2 (&X)[13]) {
+  float A0[5];
+  float2 B1[5], B2[5];
+  static_for<0, 5>([&](auto n2c) {
+    constexpr int n2 = decltype(n2c)::value;
+    float2 a1, a2;
+    rdft5w(x[n2], w[n2], x[5 + n2], w[5 + n2], x[10 + n2], w[10 + n2], x[15 + n2], w[15 + n2],
+           x[20 + n2], w[20 + n2], A0[n2], a1, a2);
+    B1[n2] = mul_w<n2, 25>(a1);
+    B2[n2] = mul_w<2 * n2, 25>(a2);
+  });
+  float r0;
+  rdft5(A0[0], A0[1], A0[2], A0[3], A0[4], r0, X[5], X[10]);
+  X[0] = {r0, 0.0f};
+  Dft<5>::run(B1);
+  X[1] = B1[0];
+  X[6] = B1[1];
+  X[11] = B1[2];
+  X[9] = cconj(B1[3]);
+  X[4] = cconj(B1[4]);
+  Dft<5>::run(B2);
+  X[2] = B2[0];
+  X[7] = B2[1];
+  X[12] = B2[2];
+  X[8] = cconj(B2[3]);
+  X[3] = cconj(B2[4]);
+}
+
 }  // namespace mia

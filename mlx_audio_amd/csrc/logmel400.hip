@@ -515,7 +515,14 @@ __global__ __launch_bounds__(w400::WG, 4) void logmel400_kernel(
 //   * the workgroup barrier is a bare s_barrier (a __syncthreads() would drain the loads in
 //     flight), and the wait for the DMA sits at the end of the sweep, counted so that the
 //     sweep's own stores stay in flight.
-// Arithmetic, its order and the output are bit-identical to logmel400_kernel.
+//   * the 16 x 25 split is the prime-factor (Good-Thomas) one: 16 and 25 are coprime, so with
+//     role n1 taking the samples (25 n1 + 16 n2) mod 400 and butterfly k2 yielding the bins
+//     k = k1 (mod 16), k = k2 (mod 25), no twiddle factors stand between the two passes (12
+//     complex products and 24 registers per lane less than the Cooley-Tukey split); the
+//     window multiply is folded into the first butterflies.  Each lane keeps the LDS addresses
+//     of its 25 samples in registers instead (the swizzle and the index wrap cost nothing).
+// The mel sweep's arithmetic equals logmel400_kernel's; the transform differs in rounding
+// (both are within 2e-6 of the float64 result on the (log10 + 4) / 4 scale).
 #ifndef W400D_SWEEP_PRIO
 #define W400D_SWEEP_PRIO 1
 #endif
@@ -539,7 +546,17 @@ static_assert((PW * 4) % 16 == 0 && (OFF_ST * 4) % 16 == 0, "DMA destinations ar
 static_assert(NW * PW * 4 <= 160 * 1024, "LDS budget");
 static_assert(EXF % 64 == 32, "frames 0/1 of a half-wave read opposite bank halves");
 // position of sample s of the wave's span in the staging area, and back (an involution)
-__device__ __forceinline__ int swz(int s) { return s ^ (((s / HOP) & 1) ? 0 : 16); }
+__device__ __forceinline__ constexpr int swz(int s) { return s ^ (((s / HOP) & 1) ? 0 : 16); }
+// Slot of bin k in a frame's power column: butterfly k2 = k mod 25 (0..12; bins with a larger
+// residue are the conjugates of bin 400 - k) leaves output k1 = k mod 16 at 13 k1 + k2.
+__device__ __forceinline__ constexpr int bin_slot(int k) {
+  int k1 = k % 16, k2 = k % 25;
+  if (k2 > 12) {
+    k1 = (16 - k1) % 16;
+    k2 = 25 - k2;
+  }
+  return 13 * k1 + k2;
+}
 }  // namespace w400d
 
 // One wave-wide LDS-DMA load: lane L's 16 bytes at gbase + voff land at lds_byte_addr + 16 L.
@@ -603,7 +620,7 @@ struct SweepCtxDma {
   int has_prev, flush, nvalid;   // (!FULL) wave-uniform; frames of the clip in this tile
   float pend_y;                  // (FULL) the previous emit's rotated value, stored one emit
   unsigned pend_off;             // later so that the rotation's latency is not waited for
-  __device__ __forceinline__ float ld(int k) const { return pr[4 * k]; }
+  __device__ __forceinline__ float ld(int k) const { return pr[4 * w400d::bin_slot(k)]; }
   __device__ __forceinline__ void store(unsigned off, float v) const {
     if (!MIA_DBG(p, 4)) *reinterpret_cast<float*>(rowp + (size_t)off) = v;
   }
@@ -687,8 +704,7 @@ __device__ __forceinline__ void dma_wave_samples(const float* __restrict__ yb, l
 template <int EPI, int BANK>
 __global__ __launch_bounds__(w400d::WG, 4) void logmel400d_kernel(
     FwdParams p, const float* __restrict__ g_y, const float* __restrict__ g_win,
-    const float2* __restrict__ g_tw, float* __restrict__ g_out, int* __restrict__ g_maxkey,
-    int* __restrict__ g_minkey) {
+    float* __restrict__ g_out, int* __restrict__ g_maxkey, int* __restrict__ g_minkey) {
   using namespace w400d;
   static_assert(BANK != 0, "the DMA kernel exists for the compiled filterbanks");
   __shared__ __attribute__((aligned(16))) float lds[NW * PW];
@@ -703,12 +719,14 @@ __global__ __launch_bounds__(w400d::WG, 4) void logmel400d_kernel(
 
   // ---- per-lane constants, held in VGPRs for the whole run of tiles ----------------------
   const int role0 = tid0 & 15;
-  float wnd[25];
-  float2 twd[13];
+  float wnd[25];       // window taps of this role's samples (25 n1 + 16 n2) mod 400
+  unsigned sadr[25];   // ... and their byte offsets in the staging area (swizzle applied)
 #pragma unroll
-  for (int r = 0; r < 25; ++r) wnd[r] = g_win[32 * role0 + r];
-#pragma unroll
-  for (int k = 1; k < 13; ++k) twd[k] = g_tw[16 * role0 + k];
+  for (int r = 0; r < 25; ++r) {
+    wnd[r] = g_win[32 * role0 + r];
+    const int j = (25 * role0 + 16 * r) % N;
+    sadr[r] = 4u * (unsigned)swz(HOP * ((tid0 & 63) >> 4) + j);
+  }
   unsigned soff[NDMA];  // sample (relative to the wave's span) behind this lane's DMA chunks
 #pragma unroll
   for (int i = 0; i < NDMA; ++i) {
@@ -716,9 +734,7 @@ __global__ __launch_bounds__(w400d::WG, 4) void logmel400d_kernel(
     soff[i] = (unsigned)swz(pos < WSPAN ? pos : 0);
   }
 #pragma unroll
-  for (int r = 0; r < 25; ++r) asm volatile("" : "+v"(wnd[r]));
-#pragma unroll
-  for (int k = 1; k < 13; ++k) asm volatile("" : "+v"(twd[k].x), "+v"(twd[k].y));
+  for (int r = 0; r < 25; ++r) asm volatile("" : "+v"(wnd[r]), "+v"(sadr[r]));
 #pragma unroll
   for (int i = 0; i < NDMA; ++i) asm volatile("" : "+v"(soff[i]));
 
@@ -762,25 +778,17 @@ __global__ __launch_bounds__(w400d::WG, 4) void logmel400d_kernel(
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    // ---- pass 1: real radix-25 over x[t + 16 r] of frame 4 wv + fi, then the step twiddle --
+    // ---- pass 1: windowed real radix-25 over this role's samples: Y[k2], k2 = 0..12 ---------
     {
       float2 y[13];
       float x[25];
-      // sample 160 fi + t + 16 r sits at 160 fi + t + 16 (r ^ e), e = 1 in the even rows
-      // fi + r / 10 of the span (the swizzle)
-      const int sel = (fi & 1) ^ 1;
-      const float* __restrict__ sp = stage + HOP * fi + role;
-      const float* __restrict__ spp = sp + 16 * sel;
-      const float* __restrict__ spm = sp - 16 * sel;
+      const char* __restrict__ sb = reinterpret_cast<const char*>(stage);
       if (MIA_DBG(p, 128)) {  // ablation: no sample reads
 #pragma unroll
         for (int r = 0; r < 25; ++r) x[r] = wnd[r];
       } else {
 #pragma unroll
-        for (int r = 0; r < 25; ++r) {
-          const int u = r ^ ((r / 10) & 1);
-          x[r] = ((u & 1) ? spm : spp)[16 * u] * wnd[r];
-        }
+        for (int r = 0; r < 25; ++r) x[r] = *reinterpret_cast<const float*>(sb + sadr[r]);
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       __builtin_amdgcn_wave_barrier();
@@ -789,9 +797,19 @@ __global__ __launch_bounds__(w400d::WG, 4) void logmel400d_kernel(
 #pragma unroll
         for (int k = 0; k < 13; ++k) y[k] = {x[2 * k], x[(2 * k + 1) % 25]};
       } else {
-        rdft25(x, y);
+        rdft25w(x, wnd, y);
+        // An infinite sample must leave NaN in every bin of its frame, as the cancellations
+        // of the reference's transform do (and as the twiddle products of the Cooley-Tukey
+        // split did); with additions only, same-signed infinities would survive as +inf.
+        // y[0] is the plain sum of the role's windowed samples: it is finite unless one of
+        // them is not.  The check is wave-uniform and false for audio.
+        const bool bad = !(__builtin_fabsf(y[0].x) < INFINITY);
+        if (__builtin_amdgcn_ballot_w64(bad) != 0) {
+          if (bad) {
 #pragma unroll
-        for (int k = 1; k < 13; ++k) y[k] = cmul(y[k], twd[k]);
+            for (int k = 0; k < 13; ++k) y[k] = {__builtin_nanf(""), __builtin_nanf("")};
+          }
+        }
       }
       float2* __restrict__ exw = reinterpret_cast<float2*>(exf + 26 * role);
       if (!MIA_DBG(p, 64)) {  // (ablation bit 64: no exchange)
@@ -806,7 +824,7 @@ __global__ __launch_bounds__(w400d::WG, 4) void logmel400d_kernel(
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 
-    // ---- pass 2: radix-16 over the roles; v[k2] = X[k1 + 25 k2] ---------------------------
+    // ---- pass 2: butterfly k2 = role (0..12): radix-16 over the roles n1; v[k1] = X[k1, k2] ----
     float pw[16];
     {
       float2 v[16];
@@ -821,7 +839,7 @@ __global__ __launch_bounds__(w400d::WG, 4) void logmel400d_kernel(
       }
       if (!MIA_DBG(p, 2)) Dft<16>::run(v);
 #pragma unroll
-      for (int k2 = 0; k2 < 16; ++k2) pw[k2] = fmaf(v[k2].x, v[k2].x, v[k2].y * v[k2].y);
+      for (int k1 = 0; k1 < 16; ++k1) pw[k1] = fmaf(v[k1].x, v[k1].x, v[k1].y * v[k1].y);
     }
     // opaque: the exchange has been read back (the power values depend on it) before
     // anything below is issued
@@ -836,17 +854,11 @@ __global__ __launch_bounds__(w400d::WG, 4) void logmel400d_kernel(
                        stage, stage_bytes);
     }
 
-    // ---- power columns of the wave's 4 frames: slot[4 * bin + fi] -------------------------
+    // ---- power columns of the wave's 4 frames: X[k1, k2] at slot[4 (13 k1 + k2) + fi] --------
     if (role < 13 && !MIA_DBG(p, 256)) {  // (ablation bit 256: no power write)
-      float* __restrict__ pa = slot + 4 * role + fi;          // bins k1 + 25 k2, k2 = 0..7
-      float* __restrict__ pb = slot + 4 * (200 - role) + fi;  // bins 400 - (k1 + 25 k2), k2 = 8..15
+      float* __restrict__ pa = slot + 4 * role + fi;
 #pragma unroll
-      for (int k2 = 0; k2 < 8; ++k2) pa[4 * 25 * k2] = pw[k2];
-      pb[0] = pw[8];
-      if (role != 0) {  // butterfly 0 repeats bins 175, 150, ... it already wrote
-#pragma unroll
-        for (int k2 = 9; k2 < 16; ++k2) pb[-4 * 25 * (k2 - 8)] = pw[k2];
-      }
+      for (int k1 = 0; k1 < 16; ++k1) pa[4 * 13 * k1] = pw[k1];
     }
   };
 
@@ -973,7 +985,7 @@ int w400_compiled_bank(const float* basis, int n_mels, int bins) {
 template <int EPI, int BANK>
 static void launch_w400d(const FwdParams& p, const W400Tables& tb, unsigned grid, hipStream_t s) {
   hipLaunchKernelGGL((logmel400d_kernel<EPI, BANK>), dim3(grid), dim3(w400d::WG), 0, s, p, p.y,
-                     tb.win16, tb.tw16, p.mout, p.clip_max_key, p.clip_min_key);
+                     tb.winp, p.mout, p.clip_max_key, p.clip_min_key);
 }
 
 template <int EPI, int BANK>

@@ -94,6 +94,7 @@ struct mia_plan {
   // extra tables of the n_fft = 400 / hop = 160 kernel (null when not applicable)
   float* d_win16 = nullptr;      // [16][32] window taps t + 16 r of role t (25 used)
   float2* d_tw16 = nullptr;      // [16][16] exp(-2 pi i t k1 / 400), k1 = 0..12 used
+  float* d_winp = nullptr;       // [16][32] window taps (25 n1 + 16 n2) mod 400 of role n1
   int* d_sweep_meta = nullptr;   // [16][16] per-wave sweep header: first bin, chunks, first filter, pre-emits
   float* d_sweep_w = nullptr;    // [16][W400_MEL_MAXC][32] per-wave sweep program (see logmel400.hip)
   int w400_bank = 0;             // 80 / 128 when the filterbank is that compiled-in Whisper bank
@@ -147,6 +148,7 @@ constexpr int kEpiStats = 3;  // internal epilogue code (the public ones are MIA
 struct W400Tables {
   const float* win16;
   const float2* tw16;
+  const float* winp;      // [16][32] window taps (25 n1 + 16 n2) mod 400 of role n1 (prime-factor split)
   const int* sweep_meta;
   const float* sweep_w;
   int compiled_bank;      // 80 / 128: the filterbank equals that compiled-in Whisper bank; else 0
