@@ -745,28 +745,68 @@ __global__ __launch_bounds__(w400d::WG, 4) void logmel400d_kernel(
   float prev[MAXR];  // the previous tile's outputs (see SweepCtxDma)
 #pragma unroll
   for (int j = 0; j < MAXR; ++j) prev[j] = 0.0f;
+  STAMP_DECL
   float* __restrict__ mine = lds + wv * PW;  // slot 0 | slot 1 | staging
   float* __restrict__ stage = mine + OFF_ST;
   const unsigned stage_bytes = (unsigned)__builtin_amdgcn_readfirstlane(
       (int)(unsigned)(unsigned long long)(stage));  // LDS byte address (low half of the flat one)
 
-  // Tiles k = 0 .. n - 1 of this workgroup's run; (b, tile) of tile k, k + 1 and k + 2.
+  // Tiles k = 0 .. n - 1 of this workgroup's run.  Two cursors walk them, each advanced by
+  // additions once per period (no per-tile 64-bit multiplies): `sw` is the tile being swept
+  // (tile k), `ld` the tile whose samples are being loaded (tile k + 2; k starts at -1).
   const int n_run = last - first;
-  auto advance = [&](int& bb, int& tt) {
-    if (++tt == p.tiles) {
-      tt = 0;
-      ++bb;
+  struct SweepCursor {
+    int b, tile;      // clip, tile of the clip
+    int left;         // frames of the clip from this tile's first on (clamped to int)
+    char* rp;         // 32 floats before (row m0 of clip b, frame 64 tile)
+    unsigned sg4;     // 4 * ((row start of (b, m0)) mod 32)
+  } sw;
+  struct LoadCursor {
+    int tile;
+    const float* yb;  // clip row
+    long long s;      // first sample of the wave's span in that tile (may be negative: padding)
+  } ld;
+  const long long clip_out_bytes = 4ll * p.n_mels * p.F;
+  const unsigned clip_sg4 = 4u * (unsigned)(((long long)p.n_mels * p.F) & 31);
+  const long long s_first = (long long)4 * wv * HOP - p.pad;
+  {
+    const long long row0 = (long long)cur_b * p.n_mels + m0;
+    sw.b = cur_b;
+    sw.tile = cur_tile;
+    sw.left = (int)min(p.F - (long long)cur_tile * FT, (long long)0x7fffffff);
+    sw.rp = reinterpret_cast<char*>(g_out + (row0 * p.F + (long long)cur_tile * FT - 32));
+    sw.sg4 = 4u * (unsigned)((row0 * p.F) & 31);
+    int lb = cur_b, lt = cur_tile + 1;  // tile 1 of the run
+    if (lt == p.tiles) lt = 0, ++lb;
+    ld.tile = lt;
+    ld.yb = g_y + (long long)lb * p.T;
+    ld.s = (long long)lt * (FT * HOP) + s_first;
+  }
+  auto advance_sweep = [&]() {
+    if (++sw.tile == p.tiles) {
+      sw.rp += clip_out_bytes - 4ll * FT * (p.tiles - 1);
+      sw.sg4 = (sw.sg4 + clip_sg4) & 124u;
+      sw.tile = 0;
+      ++sw.b;
+      sw.left = (int)min(p.F, (long long)0x7fffffff);
+    } else {
+      sw.rp += 4 * FT;
+      sw.left -= FT;
     }
   };
-  // in period k: (b0, t0) is tile k, (b1, t1) tile k + 1, (b2, t2) tile k + 2; k starts at -1
-  int b0 = 0, t0 = 0;
-  int b1 = cur_b, t1 = cur_tile;
-  int b2 = b1, t2 = t1;
-  advance(b2, t2);
+  auto advance_load = [&]() {
+    if (++ld.tile == p.tiles) {
+      ld.tile = 0;
+      ld.yb += p.T;
+      ld.s = s_first;
+    } else {
+      ld.s += FT * HOP;
+    }
+  };
 
   // ---- transform of tile kf (its samples are staged), P into slot[kf & 1]; issues the
   // loads of tile kf + 1 = clip bn, tile tn ----------------------------------------------
-  auto transform = [&](int kf, bool load_next, int bn, int tn) {
+  auto transform = [&](int kf, bool load_next) {
     int tid = tid0;
     asm volatile("" : "+v"(tid));
     const int lane = tid & 63;
@@ -820,6 +860,7 @@ __global__ __launch_bounds__(w400d::WG, 4) void logmel400d_kernel(
         for (int c = 0; c < 13; ++c) asm volatile("" ::"v"(y[c].x), "v"(y[c].y));
       }
     }
+    STAMP(2)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -846,14 +887,14 @@ __global__ __launch_bounds__(w400d::WG, 4) void logmel400d_kernel(
 #pragma unroll
     for (int k2 = 0; k2 < 16; ++k2) asm volatile("" : "+v"(pw[k2]));
 
+    STAMP(3)
     // ---- the next tile's samples: the staging area is free from here on ------------------
     if (load_next && !MIA_DBG(p, 16)) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      dma_wave_samples(g_y + (long long)bn * p.T, p.T,
-                       (long long)tn * (FT * HOP) - p.pad + 4 * wv * HOP, p.pad_mode, lane, soff,
-                       stage, stage_bytes);
+      dma_wave_samples(ld.yb, p.T, ld.s, p.pad_mode, lane, soff, stage, stage_bytes);
     }
 
+    STAMP(4)
     // ---- power columns of the wave's 4 frames: X[k1, k2] at slot[4 (13 k1 + k2) + fi] --------
     if (role < 13 && !MIA_DBG(p, 256)) {  // (ablation bit 256: no power write)
       float* __restrict__ pa = slot + 4 * role + fi;
@@ -864,25 +905,23 @@ __global__ __launch_bounds__(w400d::WG, 4) void logmel400d_kernel(
 
   // ---- mel sweep + log epilogue of tile ks = clip b, tile `tile` (lane = frame); ends with
   // the wait that retires the loads in flight ----------------------------------------------
-  auto sweep = [&](int ks, int b, int tile, bool last_of_run) {
+  auto sweep = [&](int ks, bool last_of_run) {
     int tid = tid0;
     asm volatile("" : "+v"(tid));
     const int lane = tid & 63;
-    const long long f0 = (long long)tile * FT;
-    const bool valid = f0 + lane < p.F;
-    const bool last_of_clip = tile + 1 == p.tiles;
+    const int b = sw.b;
+    const bool valid = lane < sw.left;
+    const bool last_of_clip = sw.tile + 1 == p.tiles;
     const float* __restrict__ P = lds + (ks & 1) * SL;
-    float* __restrict__ rowp = g_out + (((long long)b * p.n_mels + m0) * p.F + f0);
     if (!MIA_DBG(p, 1)) {
-      const long long row0 = (long long)b * p.n_mels + m0;
-      const int has_prev = tile > 0 && ks > 0;
+      const int has_prev = sw.tile > 0 && ks > 0;
       const int flush = last_of_clip || last_of_run;
-      const int nvalid = p.F - f0 < FT ? (int)(p.F - f0) : FT;
+      const int nvalid = sw.left < FT ? sw.left : FT;
       const int full = has_prev && !flush && nvalid == FT;
       const unsigned mhi0 = mhi, mlo0 = mlo;
       const float* __restrict__ pcol = P + (lane >> 2) * PW + (lane & 3);
-      char* __restrict__ rp = reinterpret_cast<char*>(rowp - 32);
-      const unsigned sg0 = 4u * (unsigned)((row0 * p.F) & 31), fm = 4u * (unsigned)(p.F & 31);
+      char* __restrict__ rp = sw.rp;
+      const unsigned sg0 = sw.sg4, fm = 4u * (unsigned)(p.F & 31);
       const unsigned f4 = 4u * (unsigned)p.F;
       unsigned nhi, nlo;
       if (full) {
@@ -924,34 +963,38 @@ __global__ __launch_bounds__(w400d::WG, 4) void logmel400d_kernel(
   };
 
   // ---- the first tile's samples --------------------------------------------------------------
-  dma_wave_samples(g_y + (long long)b1 * p.T, p.T,
-                   (long long)t1 * (FT * HOP) - p.pad + 4 * wv * HOP, p.pad_mode, tid0 & 63, soff,
-                   stage, stage_bytes);
+  dma_wave_samples(g_y + (long long)cur_b * p.T, p.T, (long long)cur_tile * (FT * HOP) + s_first,
+                   p.pad_mode, tid0 & 63, soff, stage, stage_bytes);
   wait_vmcnt<0>();
 
   // ---- period k = -1 .. n - 1: the sweep of tile k (k >= 0) and the transform of tile k + 1
   // (k + 1 < n), then ONE barrier ("P of tile k + 1 is complete, everyone is done sweeping tile
-  // k").  The two pieces do not depend on each other, and the waves of a SIMD take them in
-  // opposite orders (waves 4..7 and 12..15 transform first), so that one half's arithmetic
-  // runs beside the other half's LDS reads, rotations and stores instead of sixteen waves
-  // doing the same thing at once. ------------------------------------------------------------
+  // k").  The two pieces do not depend on each other; with W400D_STAGGER the waves of a SIMD
+  // take them in opposite orders (waves 4..7 and 12..15 transform first). ---------------------
   const bool transform_first = W400D_STAGGER && (wv & 4) != 0;
   for (int k = -1; k < n_run; ++k) {
     const bool has_next = k + 1 < n_run;
-    if (transform_first && has_next) transform(k + 1, k + 2 < n_run, b2, t2);
+    STAMP(0)
+    if (transform_first && has_next) transform(k + 1, k + 2 < n_run);
     if (k >= 0) {
       __builtin_amdgcn_s_setprio(W400D_SWEEP_PRIO);
-      sweep(k, b0, t0, !has_next);
+      sweep(k, !has_next);
       __builtin_amdgcn_s_setprio(0);
+      advance_sweep();
     }
-    if (!transform_first && has_next) transform(k + 1, k + 2 < n_run, b2, t2);
+    STAMP(1)
+    if (!transform_first && has_next) transform(k + 1, k + 2 < n_run);
     // Every sweep ends with the wait for the loads in flight; the opening period has no
     // sweep, and a transform-first wave reads tile 1's samples right after it.
     if (k < 0) wait_vmcnt<0>();
+    STAMP(5)
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    b0 = b1, t0 = t1;
-    b1 = b2, t1 = t2;
-    advance(b2, t2);
+    STAMP(6)
+    {
+      const int it = k;
+      STAMP_FLUSH
+    }
+    advance_load();
   }
 }
 

@@ -163,6 +163,9 @@ int launch_init_keys(int* max_keys, int* min_keys, long long n, hipStream_t s) {
 // gathered by all threads, compacted in clip order by one wave), then the workgroups
 // share the (clip, chunk) items of that list.
 constexpr int kFloorChunks = 64;  // pieces a clip is cut into
+#ifndef MIA_FLOOR_GRID
+#define MIA_FLOOR_GRID 2048
+#endif
 __global__ __launch_bounds__(256) void floor_clips_kernel(float* __restrict__ x, long long n,
                                                            long long B,
                                                            const int* __restrict__ max_keys,
@@ -246,8 +249,11 @@ int launch_floor_clips(float* x, long long B, long long n, int* max_keys, const 
     hipLaunchKernelGGL(reduce_keys_kernel, dim3(1), dim3(256), 0, s, max_keys, B);
     MIA_CHECK_HIP(hipGetLastError());
   }
+  // Every workgroup first derives the list of clips to clamp (it reads all the keys), so the
+  // grid stays small: enough workgroups to stream the clips that do need the floor, few enough
+  // that the common launch - nothing to clamp - costs a few microseconds.
   long long grid = B * kFloorChunks;  // never more workgroups than items
-  if (grid > 2048) grid = 2048;
+  if (grid > MIA_FLOOR_GRID) grid = MIA_FLOOR_GRID;
   hipLaunchKernelGGL(floor_clips_kernel, dim3((unsigned)grid), dim3(256), 0, s, x, n, B,
                      per_clip ? max_keys : max_keys + B, (long long)(per_clip ? 1 : 0),
                      min_keys, epi, top);

@@ -55,7 +55,20 @@ def test_contiguous_spectrogram_odd_tile_sizes_and_c_abi(gpu):
     sums = torch.zeros(4, dtype=torch.float64, device=gpu)
     s = torch.cuda.current_stream(gpu).cuda_stream
     assert lib.mia_normalize_rows(x.data_ptr(), 1, 0, 1e-5, x.data_ptr(), x.data_ptr(), sums.data_ptr(), s) == _lib.MIA_ERR_INVALID
-    assert lib.mia_normalize_rows(x.data_ptr(), 70000, 1, 1e-5, x.data_ptr(), x.data_ptr(), sums.data_ptr(), s) == _lib.MIA_ERR_INVALID
+    # more rows than one launch's grid takes: the entry point goes through them in pieces
+    big = torch.randn((70000, 3), device=gpu)
+    big_out = torch.empty_like(big)
+    big_st = torch.empty((70000, 2), device=gpu)
+    big_sums = torch.zeros((70000, 2), dtype=torch.float64, device=gpu)
+    assert lib.mia_normalize_rows(big.data_ptr(), 70000, 3, 1e-5, big_out.data_ptr(), big_st.data_ptr(),
+                                  big_sums.data_ptr(), s) == _lib.MIA_OK
+    torch.cuda.synchronize()
+    mean = big.double().mean(dim=1)
+    std = big.double().std(dim=1, unbiased=False)
+    np.testing.assert_allclose(big_st[:, 0].cpu().numpy(), mean.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(big_out.cpu().numpy(),
+                               ((big.double() - mean[:, None]) / (std[:, None] + 1e-5)).cpu().numpy(),
+                               rtol=2e-5, atol=2e-5)
     out = torch.empty(8, device=gpu)
     st = torch.empty(2, device=gpu)
     assert lib.mia_normalize_rows(x.data_ptr(), 1, 8, 1e-5, out.data_ptr(), st.data_ptr(), sums.data_ptr(), s) == _lib.MIA_OK
