@@ -1,5 +1,6 @@
 // extern "C" surface of libmia_hip.so: error reporting, host-side table
 // builders, plan management and the launch wrappers.
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <mutex>
@@ -221,6 +222,8 @@ static void plan_free(mia_plan* p) {
   (void)hipFree(p->d_win16);
   (void)hipFree(p->d_tw16);
   (void)hipFree(p->d_winp);
+  (void)hipFree(p->d_mfma_meta);
+  (void)hipFree(p->d_mfma_a);
   (void)hipFree(p->d_sweep_meta);
   (void)hipFree(p->d_sweep_w);
   (void)hipFree(p->d_chirp);
@@ -401,6 +404,48 @@ static int build_w400_tables(mia_plan* p, const float* window, const float* basi
   if ((rc = upload(&p->d_tw16, tw16)) != MIA_OK) return rc;
   if ((rc = upload(&p->d_sweep_meta, meta)) != MIA_OK) return rc;
   if ((rc = upload(&p->d_sweep_w, sw)) != MIA_OK) return rc;
+  // Matrix-core projection (the A/B alternative to the sweep): the filterbank in blocks of 16
+  // filters, each a 16 x K band of the matrix, K in steps of 4 bins (one
+  // v_mfma_f32_16x16x4_f32 each).  Wave w projects frames 16 (w % 4) .. + 15 for the blocks of
+  // group w / 4; the (at most 8) blocks are dealt to the 4 groups so that the steps balance.
+  if (n_mels <= 128) {
+    const int nmb = (n_mels + 15) / 16;
+    struct Blk { int mb, klo, steps; };
+    std::vector<Blk> blks;
+    for (int mb = 0; mb < nmb; ++mb) {
+      int lo = bins, hi = -1;
+      for (int m = 16 * mb; m < std::min(n_mels, 16 * mb + 16); ++m) {
+        for (int k = 0; k < bins; ++k) {
+          if (basis[(size_t)m * bins + k] != 0.0f) lo = std::min(lo, k), hi = std::max(hi, k);
+        }
+      }
+      blks.push_back({mb, hi < 0 ? 0 : lo, hi < 0 ? 0 : (hi - lo + 4) / 4});
+    }
+    std::sort(blks.begin(), blks.end(), [](const Blk& a, const Blk& b) { return a.steps > b.steps; });
+    std::vector<int> mm(4 * 2 * 4, 0);
+    for (int i = 0; i < 8; ++i) mm[(size_t)4 * i] = -1;
+    int load[4] = {0, 0, 0, 0}, cnt[4] = {0, 0, 0, 0};
+    std::vector<float> amat;
+    for (const Blk& bk : blks) {
+      int g = -1;
+      for (int c = 0; c < 4; ++c) {
+        if (cnt[c] < 2 && (g < 0 || load[c] < load[g])) g = c;
+      }
+      int* e = &mm[(size_t)(2 * g + cnt[g]) * 4];
+      e[0] = bk.mb, e[1] = bk.klo, e[2] = bk.steps, e[3] = (int)(amat.size() / 64);
+      ++cnt[g];
+      load[g] += bk.steps;
+      for (int st = 0; st < (bk.steps + 3) / 4 * 4; ++st) {  // whole chunks of 4 steps, zero-padded
+        for (int lane = 0; lane < 64; ++lane) {  // A[m = lane % 16][k = lane / 16]
+          const int m = 16 * bk.mb + lane % 16, k = bk.klo + 4 * st + lane / 16;
+          amat.push_back(st < bk.steps && m < n_mels && k < bins ? basis[(size_t)m * bins + k] : 0.0f);
+        }
+      }
+    }
+    if (amat.empty()) amat.push_back(0.0f);
+    if ((rc = upload(&p->d_mfma_meta, mm)) != MIA_OK) return rc;
+    if ((rc = upload(&p->d_mfma_a, amat)) != MIA_OK) return rc;
+  }
   return MIA_OK;
 }
 
@@ -514,6 +559,10 @@ int mia_plan_set_option(mia_plan* plan, const char* key, int value) {
     plan->opt_vgpr_staging = value != 0;
     return MIA_OK;
   }
+  if (strcmp(key, "w400_mfma_mel") == 0) {
+    plan->opt_mfma_mel = value != 0;
+    return MIA_OK;
+  }
   set_error("unknown plan option '%s'", key);
   return MIA_ERR_INVALID;
 }
@@ -522,6 +571,7 @@ int mia_plan_get_info(const mia_plan* plan, const char* key) {
   if (plan == nullptr || key == nullptr) return MIA_ERR_INVALID;
   if (strcmp(key, "w400_bank") == 0) return plan->w400_bank;
   if (strcmp(key, "w400_tables") == 0) return plan->d_sweep_meta != nullptr;
+  if (strcmp(key, "w400_mfma_tables") == 0) return plan->d_mfma_a != nullptr;
   if (strcmp(key, "compute_units") == 0) return plan->cus;
   set_error("unknown plan info '%s'", key);
   return MIA_ERR_INVALID;
@@ -742,7 +792,8 @@ static int forward_mel_dispatch(const mia_plan* plan, const FwdParams& p, hipStr
   if (plan->generic) return launch_forward_generic(plan, p, 1, fft_ws, fft_ws_bytes, s);
   if (plan->d_sweep_meta != nullptr && p.n_mels * p.F < (1LL << 30)) {
     W400Tables tb{plan->d_win16, plan->d_tw16, plan->d_winp, plan->d_sweep_meta, plan->d_sweep_w,
-                  plan->w400_bank, plan->opt_table_sweep, plan->opt_vgpr_staging, plan->cus};
+                  plan->w400_bank, plan->opt_table_sweep, plan->opt_vgpr_staging, plan->cus,
+                  plan->d_mfma_meta, plan->d_mfma_a, plan->opt_mfma_mel};
     return launch_logmel400(p, tb, s);
   }
   return launch_forward(plan, p, 1, s);

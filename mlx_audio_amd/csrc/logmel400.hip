@@ -226,6 +226,73 @@ __device__ __forceinline__ int compiled_first_filter(int wv) {
   return BANK == 128 ? kW400Start128[wv] : kW400Start80[wv];
 }
 
+// The mel projection on the matrix cores instead of the sweep (BANK = W400_MFMA; kept for
+// A/B measurements: fp32 MFMA runs at the vector rate on this chip, and the dense band has
+// ~20 x the multiply-adds of the sparse sweep).  mel = A (16 filters x K) * P (K x 16 frames)
+// by v_mfma_f32_16x16x4_f32 over the block's band of bins; wave w takes frames
+// 16 (w % 4) .. + 15 of the tile and the (at most two) filter blocks of group w / 4.
+// Operands per lane l: A[m = l % 16][k = l / 16] from the table (one coalesced 256-byte
+// load per step), B[k = l / 16][n = l % 16] from the power tile in LDS; the result's lane l
+// holds filters 4 (l / 16) + i, i = 0..3, of frame l % 16.
+constexpr int W400_MFMA = -1;
+typedef float w400_f4 __attribute__((ext_vector_type(4)));
+template <int EPI>
+__device__ __forceinline__ void mel_project_mfma(const FwdParams& p, const float* __restrict__ P,
+                                                 const int* __restrict__ meta,
+                                                 const float* __restrict__ amat, int wv, int lane,
+                                                 float* __restrict__ outb, long long f0,
+                                                 unsigned& mhi, unsigned& mlo) {
+  using namespace w400;
+  const int n = 16 * (wv & 3) + (lane & 15);  // this lane's frame of the tile
+  const bool valid = f0 + n < p.F;
+  const int* __restrict__ mt = meta + 8 * (wv >> 2);
+  const float* __restrict__ bp0 = P + (n >> 2) * PW + (n & 3) + 4 * (lane >> 4);
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int mb = mt[4 * e], klo = mt[4 * e + 1], steps = mt[4 * e + 2], aoff = mt[4 * e + 3];
+    if (mb < 0) continue;
+    const float* __restrict__ ap = amat + ((size_t)aoff * 64 + lane);
+    const float* __restrict__ bp = bp0 + 4 * klo;
+    w400_f4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+    // Steps go in chunks of 4 (the A table is zero-padded to whole chunks; the power reads of
+    // the padding steps repeat the block's last step): a chunk's 16 operands are in flight
+    // while the previous chunk multiplies.
+    constexpr int CH = 4;
+    const int nch = (steps + CH - 1) / CH;
+    float a[CH], b[CH];
+    auto fetch = [&](int c) {
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        a[j] = ap[64 * (CH * c + j)];
+        b[j] = bp[16 * min(CH * c + j, steps - 1)];
+      }
+    };
+    if (nch > 0) fetch(0);
+    for (int c = 0; c < nch; ++c) {
+      float ca[CH], cb[CH];
+#pragma unroll
+      for (int j = 0; j < CH; ++j) ca[j] = a[j], cb[j] = b[j];
+      if (c + 1 < nch) fetch(c + 1);
+#pragma unroll
+      for (int j = 0; j < CH; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ca[j], cb[j], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int mel = 16 * mb + 4 * (lane >> 4) + i;
+      float outv = acc[i];
+      if (valid && mel < p.n_mels) {
+        if (EPI != MIA_EPI_NONE) {
+          const float m = floor_keep_nan(acc[i], EPI == MIA_EPI_WHISPER ? 1e-10f : p.amin);
+          outv = log_epilogue<EPI>(p, m);
+          mhi = max(mhi, __builtin_bit_cast(unsigned, m));
+          mlo = min(mlo, __builtin_bit_cast(unsigned, m));
+        }
+        if (!MIA_DBG(p, 4)) outb[(long long)mel * p.F + f0 + n] = outv;
+      }
+    }
+  }
+}
+
 // Four consecutive samples.  Clips need not start on a 16-byte boundary (odd clip
 // lengths): the type only promises float alignment.
 struct __attribute__((packed, aligned(4))) float4_a4 {
@@ -300,11 +367,11 @@ __global__ __launch_bounds__(w400::WG, 4) void logmel400_kernel(
   // ---- mel sweep constants of this wave -------------------------------------------
   int klo = 0, nchunks = 0, m0 = 0, npre = 0;
   const float4* __restrict__ prog = nullptr;
-  if (BANK == 0) {
+  if constexpr (BANK == 0) {
     const int* __restrict__ meta = g_meta + 16 * wv;
     klo = meta[0], nchunks = meta[1], m0 = meta[2], npre = meta[3];
     prog = reinterpret_cast<const float4*>(g_sw) + wv * (W400_MEL_MAXC * W400_MEL_REC / 4);
-  } else {
+  } else if constexpr (BANK > 0) {
     m0 = compiled_first_filter<BANK>(wv);
   }
 
@@ -456,7 +523,10 @@ __global__ __launch_bounds__(w400::WG, 4) void logmel400_kernel(
       const float* __restrict__ P = lds + (it & 1) * (SL + SC);
       // wave-uniform row pointer + lane offset: the row step is scalar arithmetic
       float* __restrict__ rowp = g_out + (((long long)b * p.n_mels + m0) * p.F + f0);
-      if (BANK != 0) {
+      if constexpr (BANK == W400_MFMA) {  // g_meta / g_sw carry the projection's tables
+        mel_project_mfma<EPI>(p, P, g_meta, g_sw, wv, lane, g_out + (long long)b * p.n_mels * p.F, f0,
+                              mhi, mlo);
+      } else if (BANK != 0) {
         if (valid) {  // lanes past the clip's last frame sit the sweep out
           SweepCtx<EPI> c{p, P + (lane >> 2) * PW + (lane & 3), reinterpret_cast<char*>(rowp),
                           4u * (unsigned)lane, 4u * (unsigned)p.F, mhi, mlo};
@@ -991,7 +1061,7 @@ __global__ __launch_bounds__(w400d::WG, 4) void logmel400d_kernel(
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     STAMP(6)
     {
-      const int it = k;
+      [[maybe_unused]] const int it = k;
       STAMP_FLUSH
     }
     advance_load();
@@ -1034,7 +1104,8 @@ static void launch_w400d(const FwdParams& p, const W400Tables& tb, unsigned grid
 template <int EPI, int BANK>
 static void launch_w400(const FwdParams& p, const W400Tables& tb, unsigned grid, hipStream_t s) {
   hipLaunchKernelGGL((logmel400_kernel<EPI, BANK>), dim3(grid), dim3(w400::WG), 0, s, p, p.y,
-                     tb.win16, tb.tw16, tb.sweep_meta, tb.sweep_w, p.mout, p.clip_max_key,
+                     tb.win16, tb.tw16, BANK == W400_MFMA ? tb.mfma_meta : tb.sweep_meta,
+                     BANK == W400_MFMA ? tb.mfma_a : tb.sweep_w, p.mout, p.clip_max_key,
                      p.clip_min_key);
 }
 
@@ -1060,7 +1131,9 @@ int launch_logmel400(const FwdParams& p0, const W400Tables& tb, hipStream_t s) {
   const bool dma = bank != 0 && !tb.force_vgpr_staging &&
                    (reinterpret_cast<unsigned long long>(p.y) & 15ull) == 0 && p.T % 4 == 0 &&
                    p.pad % 4 == 0;
-  if (dma) {
+  if (tb.force_mfma && tb.mfma_a != nullptr && p.epi == MIA_EPI_WHISPER) {
+    launch_w400<MIA_EPI_WHISPER, W400_MFMA>(p, tb, (unsigned)grid, s);
+  } else if (dma) {
     if (bank == 128) launch_w400d<MIA_EPI_WHISPER, 128>(p, tb, (unsigned)grid, s);
     else launch_w400d<MIA_EPI_WHISPER, 80>(p, tb, (unsigned)grid, s);
   } else if (p.epi == MIA_EPI_WHISPER) {

@@ -105,6 +105,9 @@ struct mia_plan {
   float2* d_bspec = nullptr;     // ... and the spectrum of the convolution kernel
   int opt_table_sweep = 0;       // mia_plan_set_option("w400_table_sweep"): ablation / test knob
   int opt_vgpr_staging = 0;      // mia_plan_set_option("w400_vgpr_staging"): ablation / test knob
+  int opt_mfma_mel = 0;          // mia_plan_set_option("w400_mfma_mel"): A/B knob, matrix-core projection
+  int* d_mfma_meta = nullptr;    // tables of that projection (n_mels <= 128)
+  float* d_mfma_a = nullptr;
 };
 
 namespace mia {
@@ -155,6 +158,9 @@ struct W400Tables {
   int force_table_sweep;  // testing: take the table-driven sweep although a compiled one exists
   int force_vgpr_staging; // testing: stage the samples through registers, not by LDS-DMA
   int cus;                // compute units of the plan's device
+  const int* mfma_meta;   // matrix-core projection: [4 groups][2 blocks]{block, first bin, steps, A offset}
+  const float* mfma_a;    // ... its A operands, [step][lane], zero-padded; null: filterbank not eligible
+  int force_mfma;         // testing / A-B: project on the matrix cores instead of sweeping
 };
 
 struct InvParams {

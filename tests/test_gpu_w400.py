@@ -100,3 +100,59 @@ def test_nan_and_inf_clips_compiled_sweep():
         lib.mia_plan_set_option(plan.handle, b"w400_table_sweep", 0)
     assert np.allclose(got, want, rtol=0, atol=2e-5, equal_nan=True)
     assert np.isnan(got[1]).all() and np.isfinite(got[0]).all() and np.isfinite(got[3]).all()
+
+
+@pytest.mark.parametrize("n_mels", [80, 128, 64])
+@pytest.mark.parametrize("shape", [(3, 480000), (5, 16000), (2, 10239), (300, 4000)])
+def test_matrix_core_projection_equals_sweep(n_mels, shape):
+    """The A/B variant (v_mfma_f32_16x16x4_f32 over each 16-filter band) against the sweep on
+    the same transform: the same products, summed in bin order by both; only the grouping of
+    the four products inside one matrix instruction may differ."""
+    if n_mels == 64:
+        from mlx_audio_amd._runtime import get_plan
+        from mlx_audio_amd.primitives.mel import mel_filterbank_np
+        from mlx_audio_amd.primitives.windows import padded_window_np
+
+        basis = mel_filterbank_np(16000, 400, 64, 20.0, 7600.0, False, "slaney")
+        plan = get_plan(torch.device("cuda", 0), 400, 160, True, "constant",
+                        padded_window_np("hann", 400, 400), mel_basis=basis, power=2.0)
+    else:
+        plan = _plan(n_mels)
+    lib = _lib.lib()
+    assert lib.mia_plan_get_info(plan.handle, b"w400_mfma_tables") == 1
+    g = torch.Generator(device="cuda").manual_seed(shape[0] * 77 + n_mels)
+    y = torch.randn(shape, device="cuda", generator=g)
+    y[0, : shape[1] // 2] *= 1e-4
+    y[1] = 0.0
+    try:
+        for per_clip in (1, 0):
+            _lib.check(lib.mia_plan_set_option(plan.handle, b"w400_vgpr_staging", 1))
+            _lib.check(lib.mia_plan_set_option(plan.handle, b"w400_table_sweep", 1))
+            table = _logmel(plan, y, per_clip)
+            _lib.check(lib.mia_plan_set_option(plan.handle, b"w400_mfma_mel", 1))
+            mfma = _logmel(plan, y, per_clip)
+            _lib.check(lib.mia_plan_set_option(plan.handle, b"w400_mfma_mel", 0))
+            assert np.abs(mfma - table).max() <= 2e-6, (n_mels, shape, per_clip)
+    finally:
+        lib.mia_plan_set_option(plan.handle, b"w400_mfma_mel", 0)
+        lib.mia_plan_set_option(plan.handle, b"w400_table_sweep", 0)
+        lib.mia_plan_set_option(plan.handle, b"w400_vgpr_staging", 0)
+
+
+def test_nan_and_inf_clips_matrix_core_projection():
+    plan = _plan(128)
+    lib = _lib.lib()
+    g = torch.Generator(device="cuda").manual_seed(6)
+    y = torch.randn((4, 32000), device="cuda", generator=g)
+    y[1, 777] = float("nan")
+    y[2, 1234] = float("inf")
+    _lib.check(lib.mia_plan_set_option(plan.handle, b"w400_table_sweep", 1))
+    try:
+        want = _logmel(plan, y)
+        _lib.check(lib.mia_plan_set_option(plan.handle, b"w400_mfma_mel", 1))
+        got = _logmel(plan, y)
+    finally:
+        lib.mia_plan_set_option(plan.handle, b"w400_mfma_mel", 0)
+        lib.mia_plan_set_option(plan.handle, b"w400_table_sweep", 0)
+    assert np.allclose(got, want, rtol=0, atol=2e-6, equal_nan=True)
+    assert np.isnan(got[1]).all() and np.isnan(got[2]).all() and np.isfinite(got[0]).all()
