@@ -96,8 +96,12 @@ int mia_plan_destroy(mia_plan* plan);
  * reference.  Options: "w400_table_sweep" (1: the n_fft = 400 kernel walks its filterbank
  * from tables even when the bank is one of the two compiled-in Whisper banks; results are
  * bit-identical either way), "w400_vgpr_staging" (1: that kernel stages its samples through
- * registers instead of LDS-DMA loads; bit-identical too).  Info keys: "w400_bank" (80 / 128 when the compiled sweep
- * applies, else 0), "w400_tables" (1 when the n_fft = 400 kernel serves the plan),
+ * registers instead of LDS-DMA loads and takes the Cooley-Tukey split of the transform;
+ * results agree to float32 round-off), "w400_mfma_mel" (1: the register-staging kernel
+ * projects onto the mel bank with v_mfma_f32_16x16x4_f32 over 16-filter bands instead of
+ * sweeping; slower, kept for A/B measurements; needs n_mels <= 128).  Info keys: "w400_bank"
+ * (80 / 128 when the compiled sweep applies, else 0), "w400_tables" (1 when the n_fft = 400
+ * kernel serves the plan), "w400_mfma_tables" (1 when the matrix-core mode is available),
  * "compute_units".  Not thread-safe against launches that use the plan. */
 int mia_plan_set_option(mia_plan* plan, const char* key, int value);
 int mia_plan_get_info(const mia_plan* plan, const char* key);
