@@ -20,21 +20,24 @@ namespace mia {
 // ---------------------------------------------------------------------------
 // Configuration of one n_fft: group size and radices.
 // ---------------------------------------------------------------------------
-template <int N_, int T_, int R0_, int R1_, int R2_, int PADQ_>
+template <int N_, int T_, int R0_, int R1_, int R2_, int PADQ_, int R3_ = 1, int OCC_ = 2>
 struct FftCfg {
+  static constexpr int OCC = OCC_;                      // waves per SIMD the register budget is for
   static constexpr int N = N_, M = N_ / 2, T = T_;
-  static constexpr int R0 = R0_, R1 = R1_, R2 = R2_;
-  static constexpr int NPASS = (R2_ > 1) ? 3 : 2;
-  static constexpr int RL = (NPASS == 3) ? R2_ : R1_;   // last radix
+  static constexpr int R0 = R0_, R1 = R1_, R2 = R2_, R3 = R3_;
+  static constexpr int NPASS = 2 + (R2_ > 1) + (R3_ > 1);
+  static constexpr int RL = (NPASS == 4) ? R3_ : ((NPASS == 3) ? R2_ : R1_);   // last radix
   static constexpr int NSL = M / RL;                    // stride of last pass
   static constexpr int PADQ = PADQ_;                    // one pad slot per PADQ
   static constexpr int LBUF = M + M / PADQ_ + 2;
   static constexpr bool MULTIWAVE = (T_ > 64);
   static constexpr int GPW = MULTIWAVE ? 0 : 64 / T_;   // groups per wave
-  static_assert(R0_ * R1_ * R2_ == M, "radices must multiply to n_fft/2");
+  static_assert(R0_ * R1_ * R2_ * R3_ == M, "radices must multiply to n_fft/2");
+  static_assert(R3_ == 1 || R2_ > 1, "a fourth pass needs a third");
   static_assert(2 * T_ * RL == M, "group size must be M/(2*R_last)");
   static_assert((M / R0_) % T_ == 0, "pass 0 must split evenly");
   static_assert(NPASS == 2 || (M / R1_) % T_ == 0, "pass 1 must split evenly");
+  static_assert(NPASS < 4 || (M / R2_) % T_ == 0, "pass 2 must split evenly");
   static_assert(NSL % 2 == 0, "last stride must be even");
 
   template <int WG>
@@ -79,6 +82,51 @@ __device__ __forceinline__ void group_sync() {
   }
 }
 
+// A middle Stockham pass of radix R after passes whose radices multiply to NS: thread t takes
+// butterflies t + bb * T; twiddles of its butterflies in twm (entry 0 of a row unused).
+template <class C, int R, int NS, int NB>
+__device__ __forceinline__ void middle_pass(float2* __restrict__ buf, int t, const float2 (&twm)[NB][R]) {
+  constexpr int S = C::M / R;
+  float2 v[NB][R];
+#pragma unroll
+  for (int bb = 0; bb < NB; ++bb) {
+    const int j = t + bb * C::T;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      float2 x = buf[C::template pos_strided<S>(j, r)];
+      if (r > 0) x = cmul(x, twm[bb][r]);
+      v[bb][r] = x;
+    }
+  }
+  group_sync<C>();
+#pragma unroll
+  for (int bb = 0; bb < NB; ++bb) Dft<R>::run(v[bb]);
+#pragma unroll
+  for (int bb = 0; bb < NB; ++bb) {
+    const int j = t + bb * C::T;
+    const int base = (j / NS) * NS * R + (j % NS);
+#pragma unroll
+    for (int r = 0; r < R; ++r) buf[C::template pos_strided<NS>(base, r)] = v[bb][r];
+  }
+  group_sync<C>();
+}
+// The twiddles middle_pass needs: exp(-2 pi i (j mod NS) r / (NS R)) from the n_fft-entry table.
+template <class C, int R, int NS, int NB>
+__device__ __forceinline__ void middle_twiddles(const float2* __restrict__ tw, int tt, float2 (&twm)[NB][R]) {
+  constexpr int TWS = 2 * (C::M / (NS * R));  // step in the n_fft-entry table
+#pragma unroll
+  for (int bb = 0; bb < NB; ++bb) {
+    const int jm = (tt + bb * C::T) % NS;
+#pragma unroll
+    for (int r = 1; r < R; ++r) twm[bb][r] = tw[jm * r * TWS];
+  }
+#pragma unroll
+  for (int bb = 0; bb < NB; ++bb) {
+#pragma unroll
+    for (int r = 1; r < R; ++r) asm volatile("" : "+v"(twm[bb][r].x), "+v"(twm[bb][r].y));
+  }
+}
+
 // Which registers pair up in the split step for thread 0 of a group (it owns
 // the two self-paired butterflies 0 and NSL/2).  Slot s yields bins k and M-k.
 struct T0Pair {
@@ -97,7 +145,7 @@ constexpr T0Pair t0_pair(int s) {
 }
 
 template <class C, int MODE, int WG, int ITERS>
-__global__ __launch_bounds__(WG, 2) void fwd_kernel(FwdParams p) {
+__global__ __launch_bounds__(WG, C::OCC) void fwd_kernel(FwdParams p) {
   constexpr int M = C::M, T = C::T, N = C::N;
   constexpr int G = C::template groups<WG>();
   constexpr int FT = G * ITERS;
@@ -121,10 +169,12 @@ __global__ __launch_bounds__(WG, 2) void fwd_kernel(FwdParams p) {
   // load costs the texture addresser as much as a 16-byte-per-lane data load, and the
   // passes below would issue one per element).
   constexpr int R0 = C::R0, S0 = M / R0, NB0 = S0 / T;
-  constexpr int R1 = C::R1, S1 = M / R1, NB1 = (C::NPASS == 3) ? S1 / T : 1;
+  constexpr int R1 = C::R1, S1 = M / R1, NB1 = (C::NPASS >= 3) ? S1 / T : 1;
+  constexpr int R2 = C::R2, S2 = M / R2, NB2 = (C::NPASS == 4) ? S2 / T : 1;
   constexpr int RL = C::RL, NSL = C::NSL;
   float2 wn[NB0][R0];        // window taps of the thread's sample pairs
-  float2 tw1[NB1][R1];       // middle-pass twiddles (3-pass plans)
+  float2 tw1[NB1][R1];       // middle-pass twiddles (3- and 4-pass plans)
+  float2 tw2[NB2][R2];       // second middle pass (4-pass plans)
   float2 twa[RL], twb[RL];   // last-pass twiddles of butterflies t and NSL - t
   float2 tws[RL];            // split-step twiddles
   {
@@ -142,6 +192,10 @@ __global__ __launch_bounds__(WG, 2) void fwd_kernel(FwdParams p) {
 #pragma unroll
         for (int r = 1; r < R1; ++r) tw1[bb][r] = tw[jm * r * TWS];
       }
+    }
+    if constexpr (C::NPASS == 4) {
+      middle_twiddles<C, R1, C::R0, NB1>(tw, tt, tw1);
+      middle_twiddles<C, R2, C::R0 * C::R1, NB2>(tw, tt, tw2);
     }
     const int jA = tt, jB = tt == 0 ? NSL / 2 : NSL - tt;
 #pragma unroll
@@ -331,7 +385,7 @@ __global__ __launch_bounds__(WG, 2) void fwd_kernel(FwdParams p) {
       }
       group_sync<C>();
 
-      // ---- middle pass (3-pass plans) ---------------------------------------
+      // ---- middle passes (3- and 4-pass plans) -------------------------------
       if constexpr (C::NPASS == 3) {
         constexpr int R = R1, S = S1, NB = NB1, NS = C::R0;
         float2 v[NB][R];
@@ -356,6 +410,10 @@ __global__ __launch_bounds__(WG, 2) void fwd_kernel(FwdParams p) {
           for (int r = 0; r < R; ++r) buf[C::template pos_strided<NS>(base, r)] = v[bb][r];
         }
         group_sync<C>();
+      }
+      if constexpr (C::NPASS == 4) {
+        middle_pass<C, R1, C::R0, NB1>(buf, t, tw1);
+        middle_pass<C, R2, C::R0 * C::R1, NB2>(buf, t, tw2);
       }
 
       // ---- last pass: butterflies t and NSL - t ------------------------------
@@ -580,9 +638,20 @@ using Cfg256 = FftCfg<256, 8, 16, 8, 1, 16>;
 using Cfg400 = FftCfg<400, 10, 20, 10, 1, 20>;
 using Cfg512 = FftCfg<512, 32, 8, 8, 4, 8>;
 using Cfg800 = FftCfg<800, 10, 20, 20, 1, 20>;
-using Cfg1024 = FftCfg<1024, 32, 8, 8, 8, 8>;
+// 1024 and 4096 points: eight points per thread and pass (four passes of radix 8 / 4, a frame
+// is one / four whole waves): half the per-thread state of a three-pass plan and no spills.
+// Measured against the three-pass plans <1024, 32, 8, 8, 8> and <4096, 128, 16, 16, 8> on one
+// box: CLAP 1.77 -> 1.56 ms, HTDemucs round trip 19.2 -> 16.0 ms.  The same shape for 2048
+// points (<2048, 128, 8, 8, 4, 8, 4>: a frame is two waves, workgroup barriers between the
+// passes) is slower than the one-wave three-pass plan (MFCC 17.2 against 14.2 ms), and capping
+// the registers for four waves per SIMD spills 25 - 90 of them and loses everywhere.
+using Cfg1024 = FftCfg<1024, 64, 8, 4, 4, 8, 4>;
 using Cfg2048 = FftCfg<2048, 64, 16, 8, 8, 16>;
-using Cfg4096 = FftCfg<4096, 128, 16, 16, 8, 16>;
+using Cfg4096 = FftCfg<4096, 256, 8, 8, 8, 8, 4>;
+#define MIA_FWD_BIG(X) \
+  X(1024, Cfg1024, 512, 2) \
+  X(2048, Cfg2048, 256, 2) \
+  X(4096, Cfg4096, 256, 4)
 
 template <class C, int MODE, int WG, int ITERS>
 static int launch_cfg(const FwdParams& p0, hipStream_t s) {
@@ -646,9 +715,7 @@ static int launch_cfg(const FwdParams& p0, hipStream_t s) {
   X(400, Cfg400, 256, 2)  \
   X(512, Cfg512, 256, 4)  \
   X(800, Cfg800, 128, 2)  \
-  X(1024, Cfg1024, 256, 2) \
-  X(2048, Cfg2048, 256, 2) \
-  X(4096, Cfg4096, 256, 2)
+  MIA_FWD_BIG(X)
 
 template <int MODE>
 static int dispatch_mode(int n_fft, const FwdParams& p, hipStream_t s) {

@@ -12,18 +12,20 @@
 
 namespace mia {
 
-template <int N_, int T_, int R0_, int R1_, int R2_, int PADQ_>
+template <int N_, int T_, int R0_, int R1_, int R2_, int PADQ_, int R3_ = 1>
 struct InvCfg {
   static constexpr int N = N_, M = N_ / 2, T = T_;
-  static constexpr int R0 = R0_, R1 = R1_, R2 = R2_;
-  static constexpr int NPASS = (R2_ > 1) ? 3 : 2;
-  static constexpr int RL = (NPASS == 3) ? R2_ : R1_;
+  static constexpr int R0 = R0_, R1 = R1_, R2 = R2_, R3 = R3_;
+  static constexpr int NPASS = 2 + (R2_ > 1) + (R3_ > 1);
+  static constexpr int RL = (NPASS == 4) ? R3_ : ((NPASS == 3) ? R2_ : R1_);
   static constexpr int S0 = M / R0_;
   static constexpr int PADQ = PADQ_;
   static constexpr int LBUF = M + M / PADQ_ + 2;
   static constexpr bool MULTIWAVE = (T_ > 64);
   static constexpr int GPW = MULTIWAVE ? 0 : 64 / T_;
-  static_assert(R0_ * R1_ * R2_ == M, "radices must multiply to n_fft/2");
+  static_assert(R0_ * R1_ * R2_ * R3_ == M, "radices must multiply to n_fft/2");
+  static_assert(R3_ == 1 || R2_ > 1, "a fourth pass needs a third");
+  static_assert(NPASS < 4 || (M / R2_) % T_ == 0, "pass 2 must split evenly");
   static_assert(2 * T_ == S0, "group size must be M/(2*R0)");
   static_assert(S0 % 2 == 0, "first stride must be even");
   static_assert((M / RL) % T_ == 0, "last pass must split evenly");
@@ -205,9 +207,10 @@ __device__ __forceinline__ void inverse_frame(const InvParams& p, const float2* 
   }
   inv_group_sync<C>();
 
-  // ---- middle pass -----------------------------------------------------------
-  if constexpr (C::NPASS == 3) {
-    constexpr int R = C::R1, S = M / R, NB = S / T, NS = C::R0;
+  // ---- middle passes (one in 3-pass plans, two in 4-pass plans) -------------------
+  auto middle = [&](auto Rc, auto NSc) {
+    constexpr int R = decltype(Rc)::value, NS = decltype(NSc)::value;
+    constexpr int S = M / R, NB = S / T;
     constexpr int TWS = 2 * (M / (NS * R));
     float2 v[NB][R];
 #pragma unroll
@@ -232,6 +235,10 @@ __device__ __forceinline__ void inverse_frame(const InvParams& p, const float2* 
       for (int r = 0; r < R; ++r) buf[C::template pos_strided<NS>(base, r)] = v[bb][r];
     }
     inv_group_sync<C>();
+  };
+  if constexpr (C::NPASS >= 3) middle(std::integral_constant<int, C::R1>{}, std::integral_constant<int, C::R0>{});
+  if constexpr (C::NPASS == 4) {
+    middle(std::integral_constant<int, C::R2>{}, std::integral_constant<int, C::R0 * C::R1>{});
   }
 
   // ---- last pass: outputs are time samples ------------------------------------
@@ -471,7 +478,17 @@ using Inv512 = InvCfg<512, 32, 4, 8, 8, 4>;
 using Inv800 = InvCfg<800, 10, 20, 20, 1, 20>;
 using Inv1024 = InvCfg<1024, 32, 8, 8, 8, 8>;
 using Inv2048 = InvCfg<2048, 64, 8, 8, 16, 8>;
+#ifndef MIA_INV4096_V2
+#define MIA_INV4096_V2 0
+#endif
+#if MIA_INV4096_V2
+// eight points per thread and pass, a frame is four whole waves (see Cfg4096 of the forward kernel)
+using Inv4096 = InvCfg<4096, 256, 4, 8, 8, 8, 8>;
+constexpr int kInv4096Iters = 4, kInv4096FusedIters = 4;
+#else
 using Inv4096 = InvCfg<4096, 128, 8, 16, 16, 8>;
+constexpr int kInv4096Iters = 4, kInv4096FusedIters = 2;
+#endif
 
 template <class C, int WG, int ITERS>
 static int launch_inv(const InvParams& p0, hipStream_t s) {
@@ -542,7 +559,7 @@ int launch_istft_fused(const mia_plan* plan, const InvParams& p, hipStream_t s) 
   switch (plan->n_fft) {
     case 1024: return launch_fused<Inv1024, 256, 2>(p, s);
     case 2048: return launch_fused<Inv2048, 256, 2>(p, s);
-    case 4096: return launch_fused<Inv4096, 256, 2>(p, s);
+    case 4096: return launch_fused<Inv4096, 256, kInv4096FusedIters>(p, s);
     default:
       set_error("n_fft=%d has no fused inverse", plan->n_fft);
       return MIA_ERR_UNSUPPORTED;
@@ -557,7 +574,7 @@ int launch_inverse(const mia_plan* plan, const InvParams& p, hipStream_t s) {
     case 800: return launch_inv<Inv800, 128, 4>(p, s);
     case 1024: return launch_inv<Inv1024, 256, 4>(p, s);
     case 2048: return launch_inv<Inv2048, 256, 4>(p, s);
-    case 4096: return launch_inv<Inv4096, 256, 4>(p, s);
+    case 4096: return launch_inv<Inv4096, 256, kInv4096Iters>(p, s);
     default:
       set_error("n_fft=%d has no compiled FFT plan", plan->n_fft);
       return MIA_ERR_UNSUPPORTED;

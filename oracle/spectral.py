@@ -622,6 +622,55 @@ def clap_padded_mel(audio: np.ndarray, sample_rate: int = 48000, n_fft: int = 10
     return np.stack([mel, mel, mel, mel], axis=0)
 
 
+def bilinear_resize(img: np.ndarray, out_h: int, out_w: int) -> np.ndarray:
+    """torch.nn.functional.interpolate(mode="bilinear", align_corners=False) on a 2-D float32
+    array, which is what models/clap/feature_extractor.py:265-272 calls: source coordinate
+    (dst + 0.5) * in/out - 0.5 clamped at 0, lower neighbour floor(), upper neighbour clamped to
+    the last row / column, weights in float32, rows blended after columns."""
+    img = np.asarray(img, np.float32)
+    in_h, in_w = img.shape
+
+    def axis(n_in, n_out):
+        scale = np.float32(n_in) / np.float32(n_out)
+        # scale * (dst + 0.5) - 0.5 with one rounding (the compiled library fuses it)
+        src = (np.float64(scale) * (np.arange(n_out, dtype=np.float64) + 0.5) - 0.5).astype(np.float32)
+        src = np.maximum(src, np.float32(0.0))
+        i0 = np.minimum(src.astype(np.int64), n_in - 1)
+        i1 = np.minimum(i0 + 1, n_in - 1)
+        l1 = (src - i0.astype(np.float32)).astype(np.float32)
+        return i0, i1, np.float32(1.0) - l1, l1
+
+    h0, h1, hl0, hl1 = axis(in_h, out_h)
+    w0, w1, wl0, wl1 = axis(in_w, out_w)
+    top = img[h0][:, w0] * wl0 + img[h0][:, w1] * wl1
+    bot = img[h1][:, w0] * wl0 + img[h1][:, w1] * wl1
+    return (hl0[:, None] * top + hl1[:, None] * bot).astype(np.float32)
+
+
+def clap_fusion_mel(audio: np.ndarray, rng, sample_rate: int = 48000, n_fft: int = 1024,
+                    hop_length: int = 480, n_mels: int = 64, max_length_s: float = 10.0,
+                    dtype=np.float32):
+    """models/clap/feature_extractor.py:233-277 (`_compute_fusion_mel`): the full mel, three
+    crops of chunk_frames frames whose starts are drawn from the thirds of the admissible
+    range (front, middle, back, in that order; the reference draws from NumPy's global
+    generator, here from `rng`), and the bilinear shrink of the full mel as channel 0.
+    Returns ([4, chunk_frames, n_mels], (front, middle, back) start frames)."""
+    mel = clap_mel(audio, sample_rate, n_fft, hop_length, n_mels, dtype=dtype)
+    chunk = int(max_length_s * sample_rate) // hop_length + 1
+    total = mel.shape[0]
+    if chunk >= total:
+        return np.stack([mel, mel, mel, mel], axis=0), (0, 0, 0)
+    ranges = np.array_split(list(range(0, total - chunk + 1)), 3)
+    if len(ranges[1]) == 0:
+        ranges[1] = [0]
+    if len(ranges[2]) == 0:
+        ranges[2] = [0]
+    starts = tuple(int(rng.choice(r)) for r in ranges)
+    crops = [mel[s:s + chunk, :] for s in starts]
+    shrink = bilinear_resize(mel.astype(np.float32), chunk, n_mels)
+    return np.stack([shrink, *crops], axis=0).astype(np.float32), starts
+
+
 def htdemucs_normalize(mix, spec, eps=1e-5):
     """models/demucs/model.py:206-233: complex-as-channels planes (re_ch0, im_ch0, re_ch1, ...),
     mean / population std over each batch item, std + eps; the waveform likewise."""

@@ -231,6 +231,21 @@ def test_clap_features(gpu):
         assert min(d) <= 1e-3
 
 
+@pytest.mark.parametrize("extra", [96000, 480000 * 2 + 777, 481])
+def test_clap_fusion_stack_against_oracle(gpu, extra):
+    """All four channels of the fusion stack of a long clip (feature_extractor.py:233-277)
+    against the oracle's restatement with the same generator: the bilinear shrink of the full
+    mel (channel 0) and the three crops at the same start frames."""
+    from mlx_audio_amd.frontends import CLAPFeatureExtractor
+
+    long = _noise(480000 + extra, 20 + extra % 7)
+    fe = CLAPFeatureExtractor(rng=np.random.default_rng(5))
+    got = fe([torch.from_numpy(long).to(gpu)])["input_features"][0].cpu().numpy()
+    want, starts = o.clap_fusion_mel(long, np.random.default_rng(5))
+    assert got.shape == want.shape == (4, 1001, 64)
+    np.testing.assert_allclose(got, want, rtol=0, atol=2e-3)  # dB values; the tolerance of the dB tests
+
+
 @pytest.mark.parametrize("T", [400, 401, 1000, 10239, 10240, 10241, 16001, 20479, 20483])
 def test_logmel_whisper_awkward_lengths(gpu, T):
     """Clip lengths around the 64-frame tile size, odd lengths (clips after the first are then

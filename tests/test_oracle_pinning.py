@@ -377,3 +377,36 @@ def test_float32_error_budget():
     a = o.compute_log_mel_spectrogram(x, n_mels=128)
     b = o.compute_log_mel_spectrogram(x, n_mels=128, dtype=np.float64)
     assert np.abs(a - b).max() < 1e-5
+
+
+@pytest.mark.parametrize("shape,out", [((1201, 64), (1001, 64)), ((3000, 64), (1001, 64)), ((7, 5), (3, 5)),
+                                        ((1002, 64), (1001, 64)), ((50, 8), (20, 16))])
+def test_bilinear_resize_matches_torch(shape, out):
+    """The shrink of the CLAP fusion stack (feature_extractor.py:265-272) is torch's bilinear
+    interpolate; the restatement reproduces it to float32 rounding of three blends."""
+    rng = np.random.default_rng(shape[0])
+    img = (rng.standard_normal(shape) * 30 - 40).astype(np.float32)
+    want = torch.nn.functional.interpolate(torch.from_numpy(img)[None, None], size=list(out), mode="bilinear",
+                                           align_corners=False)[0, 0].numpy()
+    got = o.bilinear_resize(img, *out)
+    assert got.shape == want.shape
+    np.testing.assert_allclose(got, want, rtol=0, atol=2e-5)
+
+
+def test_clap_fusion_structure():
+    rng = np.random.default_rng(3)
+    audio = rng.standard_normal(480000 + 123456).astype(np.float32)
+    full = o.clap_mel(audio)
+    stack, starts = o.clap_fusion_mel(audio, np.random.default_rng(11))
+    chunk = 480000 // 480 + 1
+    assert stack.shape == (4, chunk, 64)
+    n = full.shape[0] - chunk + 1
+    thirds = np.array_split(np.arange(n), 3)
+    for c, s in enumerate(starts):
+        assert s in thirds[c]
+        assert np.array_equal(stack[1 + c], full[s:s + chunk])
+    np.testing.assert_allclose(stack[0], o.bilinear_resize(full, chunk, 64), rtol=0, atol=0)
+    # audio that frames to no more than one chunk: four copies of its mel
+    short = rng.standard_normal(480000).astype(np.float32)
+    stack2, _ = o.clap_fusion_mel(short, np.random.default_rng(0))
+    assert np.array_equal(stack2[0], stack2[3]) and stack2.shape == (4, 1001, 64)
