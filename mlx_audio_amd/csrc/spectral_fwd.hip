@@ -645,12 +645,21 @@ using Cfg800 = FftCfg<800, 10, 20, 20, 1, 20>;
 // points (<2048, 128, 8, 8, 4, 8, 4>: a frame is two waves, workgroup barriers between the
 // passes) is slower than the one-wave three-pass plan (MFCC 17.2 against 14.2 ms), and capping
 // the registers for four waves per SIMD spills 25 - 90 of them and loses everywhere.
+#ifdef MIA_FWD2048_V2
+#define MIA_FWD2048_ITERS 4
+#else
+#define MIA_FWD2048_ITERS 2
+#endif
 using Cfg1024 = FftCfg<1024, 64, 8, 4, 4, 8, 4>;
+#ifdef MIA_FWD2048_V2
+using Cfg2048 = FftCfg<2048, 128, 8, 8, 4, 8, 4>;
+#else
 using Cfg2048 = FftCfg<2048, 64, 16, 8, 8, 16>;
+#endif
 using Cfg4096 = FftCfg<4096, 256, 8, 8, 8, 8, 4>;
 #define MIA_FWD_BIG(X) \
   X(1024, Cfg1024, 512, 2) \
-  X(2048, Cfg2048, 256, 2) \
+  X(2048, Cfg2048, 256, MIA_FWD2048_ITERS) \
   X(4096, Cfg4096, 256, 4)
 
 template <class C, int MODE, int WG, int ITERS>

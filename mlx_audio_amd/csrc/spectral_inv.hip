@@ -58,6 +58,17 @@ struct InvCfg {
   }
 };
 
+// Complex products with the rounding spelled out (one product rounded, the other fused), so
+// that every kernel built on inverse_frame gives the same bits whether its twiddle operand
+// sits in a register or comes from the table - left to the compiler, the choice of which
+// product to fuse follows the operand's origin.
+__device__ __forceinline__ float2 cmul_x(float2 a, float2 w) {
+  return {__builtin_fmaf(a.x, w.x, -(a.y * w.y)), __builtin_fmaf(a.x, w.y, a.y * w.x)};
+}
+__device__ __forceinline__ float2 cmul_conj_x(float2 a, float2 w) {  // a * conj(w)
+  return {__builtin_fmaf(a.x, w.x, a.y * w.y), __builtin_fmaf(a.y, w.x, -(a.x * w.y))};
+}
+
 template <class C>
 __device__ __forceinline__ void inv_group_sync() {
   if constexpr (C::MULTIWAVE) {
@@ -115,15 +126,78 @@ __device__ __forceinline__ void fetch_bins(FrameBins<C>& fb, const InvParams& p,
   if (valid && t0) fb.xh = xs[(long long)(M / 2) * p.sk];
 }
 
+// Every twiddle factor a thread needs for a frame, for kernels that keep them in registers
+// across their run of frames (the table loads otherwise sit in front of every pass).
+template <class C>
+struct FrameTwiddles {
+  static constexpr int NB1 = C::NPASS >= 3 ? (C::M / C::R1) / C::T : 1;
+  static constexpr int NB2 = C::NPASS == 4 ? (C::M / C::R2) / C::T : 1;
+  static constexpr int NBL = (C::M / C::RL) / C::T;
+  float2 p0[C::R0], m1[NB1][C::R1], m2[NB2][C::R2], pl[NBL][C::RL];
+  __device__ __forceinline__ void load(const float2* __restrict__ tw, int t) {
+    constexpr int M = C::M, T = C::T, S0 = C::S0;
+    static_for<0, C::R0>([&](auto sc) {
+      constexpr int s = decltype(sc)::value;
+      constexpr T0Slot ts = t0_slot<C::R0>(s);
+      p0[s] = tw[t == 0 ? ts.k_half * (S0 / 2) : t + S0 * s];
+    });
+    if constexpr (C::NPASS >= 3) {
+      constexpr int NS = C::R0, TWS = 2 * (M / (NS * C::R1));
+#pragma unroll
+      for (int bb = 0; bb < NB1; ++bb) {
+#pragma unroll
+        for (int r = 1; r < C::R1; ++r) m1[bb][r] = tw[((t + bb * T) % NS) * r * TWS];
+      }
+    }
+    if constexpr (C::NPASS == 4) {
+      constexpr int NS = C::R0 * C::R1, TWS = 2 * (M / (NS * C::R2));
+#pragma unroll
+      for (int bb = 0; bb < NB2; ++bb) {
+#pragma unroll
+        for (int r = 1; r < C::R2; ++r) m2[bb][r] = tw[((t + bb * T) % NS) * r * TWS];
+      }
+    }
+#pragma unroll
+    for (int bb = 0; bb < NBL; ++bb) {
+#pragma unroll
+      for (int r = 1; r < C::RL; ++r) pl[bb][r] = tw[2 * (t + bb * T) * r];
+    }
+    // opaque from here on: never re-fetched inside the loop
+#pragma unroll
+    for (int s = 0; s < C::R0; ++s) asm volatile("" : "+v"(p0[s].x), "+v"(p0[s].y));
+    if constexpr (C::NPASS >= 3) {
+#pragma unroll
+      for (int bb = 0; bb < NB1; ++bb) {
+#pragma unroll
+        for (int r = 1; r < C::R1; ++r) asm volatile("" : "+v"(m1[bb][r].x), "+v"(m1[bb][r].y));
+      }
+    }
+    if constexpr (C::NPASS == 4) {
+#pragma unroll
+      for (int bb = 0; bb < NB2; ++bb) {
+#pragma unroll
+        for (int r = 1; r < C::R2; ++r) asm volatile("" : "+v"(m2[bb][r].x), "+v"(m2[bb][r].y));
+      }
+    }
+#pragma unroll
+    for (int bb = 0; bb < NBL; ++bb) {
+#pragma unroll
+      for (int r = 1; r < C::RL; ++r) asm volatile("" : "+v"(pl[bb][r].x), "+v"(pl[bb][r].y));
+    }
+  }
+};
+
 // `fb` holds this frame's bins on entry if fb.ready (else they are fetched here), and on
 // exit the bins of the frame at `xs_next` (fetched behind the last pass's LDS reads, so
 // that their latency hides behind the last butterflies and the stores).
-template <class C, bool TO_BUF, class Sink>
+// `rt`: the thread's twiddles in registers, or nullptr (then they come from the table `tw`).
+template <class C, bool TO_BUF, bool RT, class Sink>
 __device__ __forceinline__ void inverse_frame(const InvParams& p, const float2* __restrict__ tw,
                                               float2* __restrict__ buf,
                                               const float2* __restrict__ xs, bool valid, int t,
                                               FrameBins<C>& fb, const float2* __restrict__ xs_next,
-                                              bool valid_next, Sink sink) {
+                                              bool valid_next, Sink sink,
+                                              const FrameTwiddles<C>* rt = nullptr) {
   constexpr int M = C::M, T = C::T;
   const bool t0 = (t == 0);
   const float inv_m = 1.0f / float(M);
@@ -143,16 +217,22 @@ __device__ __forceinline__ void inverse_frame(const InvParams& p, const float2* 
         xk.y = 0.0f;
         xm.y = 0.0f;
       }
-      const float2 w = tw[k];
+      float2 w;
+      if constexpr (RT) w = rt->p0[s]; else w = tw[k];
       // E = (X[k] + conj X[M-k])/2, O = conj(w) (X[k] - conj X[M-k])/2,
       // Z[k] = E + iO, Z[M-k] = conj(E) + i conj(O).  The 1/2 is folded
       // into the final scale.
       const float2 E = {xk.x + xm.x, xk.y - xm.y};
       const float2 D = {xk.x - xm.x, xk.y + xm.y};
-      const float2 O = cmul_conj(D, w);
+      const float2 O = cmul_conj_x(D, w);
       zk[s] = {E.x - O.y, E.y + O.x};
       zmk[s] = {E.x + O.y, O.x - E.y};
     }
+    // The bins are consumed: the next frame's are fetched here, so that their way from memory
+    // is covered by the remaining passes (behind the last pass there is too little left).
+    const float2 xh_cur = fb.xh;
+    fb.ready = xs_next != nullptr;
+    if (fb.ready) fetch_bins<C>(fb, p, xs_next, valid_next, t);
     float2 A[R], Bv[R];
     // generic threads: A[s] = Z[t + S0 s], B[R-1-s] = Z[M - k_s]
 #pragma unroll
@@ -174,7 +254,7 @@ __device__ __forceinline__ void inverse_frame(const InvParams& p, const float2* 
         }
       });
       // the self-paired bin M/2: Z = conj(X[M/2]) (times 2 for the folded 1/2)
-      const float2 xh = fb.xh;
+      const float2 xh = xh_cur;
       const float2 zh = {2.0f * xh.x, -2.0f * xh.y};
       if constexpr (R % 2 == 0) {
         A0[R / 2] = zh;
@@ -208,8 +288,8 @@ __device__ __forceinline__ void inverse_frame(const InvParams& p, const float2* 
   inv_group_sync<C>();
 
   // ---- middle passes (one in 3-pass plans, two in 4-pass plans) -------------------
-  auto middle = [&](auto Rc, auto NSc) {
-    constexpr int R = decltype(Rc)::value, NS = decltype(NSc)::value;
+  auto middle = [&](auto Rc, auto NSc, auto Wc) {
+    constexpr int R = decltype(Rc)::value, NS = decltype(NSc)::value, WHICH = decltype(Wc)::value;
     constexpr int S = M / R, NB = S / T;
     constexpr int TWS = 2 * (M / (NS * R));
     float2 v[NB][R];
@@ -220,7 +300,13 @@ __device__ __forceinline__ void inverse_frame(const InvParams& p, const float2* 
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         float2 x = buf[C::template pos_strided<S>(j, r)];
-        if (r > 0) x = cmul(x, tw[jm * r * TWS]);
+        if (r > 0) {
+          if constexpr (RT) {
+            if constexpr (WHICH == 1) x = cmul_x(x, rt->m1[bb][r]); else x = cmul_x(x, rt->m2[bb][r]);
+          } else {
+            x = cmul_x(x, tw[jm * r * TWS]);
+          }
+        }
         v[bb][r] = x;
       }
     }
@@ -236,9 +322,13 @@ __device__ __forceinline__ void inverse_frame(const InvParams& p, const float2* 
     }
     inv_group_sync<C>();
   };
-  if constexpr (C::NPASS >= 3) middle(std::integral_constant<int, C::R1>{}, std::integral_constant<int, C::R0>{});
+  if constexpr (C::NPASS >= 3) {
+    middle(std::integral_constant<int, C::R1>{}, std::integral_constant<int, C::R0>{},
+           std::integral_constant<int, 1>{});
+  }
   if constexpr (C::NPASS == 4) {
-    middle(std::integral_constant<int, C::R2>{}, std::integral_constant<int, C::R0 * C::R1>{});
+    middle(std::integral_constant<int, C::R2>{}, std::integral_constant<int, C::R0 * C::R1>{},
+           std::integral_constant<int, 2>{});
   }
 
   // ---- last pass: outputs are time samples ------------------------------------
@@ -251,13 +341,13 @@ __device__ __forceinline__ void inverse_frame(const InvParams& p, const float2* 
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         float2 x = buf[C::template pos_strided<NS>(j, r)];
-        if (r > 0) x = cmul(x, tw[2 * j * r]);
+        if (r > 0) {
+          if constexpr (RT) x = cmul_x(x, rt->pl[bb][r]); else x = cmul_x(x, tw[2 * j * r]);
+        }
         v[bb][r] = x;
       }
     }
     inv_group_sync<C>();  // buf is free again
-    fb.ready = xs_next != nullptr;
-    if (fb.ready) fetch_bins<C>(fb, p, xs_next, valid_next, t);
 #pragma unroll
     for (int bb = 0; bb < NB; ++bb) Dft<R>::run(v[bb]);
     const float sc = 0.5f * inv_m;
@@ -271,7 +361,7 @@ __device__ __forceinline__ void inverse_frame(const InvParams& p, const float2* 
         if constexpr (TO_BUF) {
           buf[j + r * NS] = o;
         } else {
-          sink(j + r * NS, o);
+          sink(j + r * NS, o, bb + NB * r);  // third argument: (n - t) / T, a constant after unrolling
         }
       }
     }
@@ -299,6 +389,9 @@ __global__ __launch_bounds__(WG) void inv_kernel(InvParams p) {
 
   if (!active) return;
   FrameBins<C> fb;
+  constexpr bool RT = C::NPASS == 4;  // the lean plans keep their twiddles in registers
+  FrameTwiddles<C> rt;
+  if constexpr (RT) rt.load(tw, t);
   for (int it = 0; it < ITERS; ++it) {
     const long long f = f0 + it * G + g;
     const bool valid = f < p.F;
@@ -309,140 +402,145 @@ __global__ __launch_bounds__(WG) void inv_kernel(InvParams p) {
     // (no prefetch of the next frame's bins here: it pushes the 4096-point plan past
     // 256 VGPRs, measured 2.43 against 2.24 ms on the round-trip workload)
     fb.ready = false;
-    inverse_frame<C, false>(p, tw, buf, xs, valid, t, fb, nullptr, false,
-                            [&](int n, float2 v) {
-                              if (valid) orow[n] = v;
-                            });
+    inverse_frame<C, false, RT>(
+        p, tw, buf, xs, valid, t, fb, nullptr, false,
+        [&](int n, float2 v, int) {
+          if (valid) orow[n] = v;
+        },
+        &rt);
   }
 }
 
-// Fused istft for hop = n_fft / 4 with hop a multiple of the workgroup size: inverse FFT
-// + windowed overlap-add + normalisation by the window envelope, no frame workspace.
-// A persistent workgroup walks a contiguous run of FT-frame tiles; within a row it
-// carries the n_fft - hop samples that later frames still add to in an LDS ring, and
-// when it starts in the middle of a row it first re-transforms (without storing) the
-// tile whose frames reach into its run.  Thread `tid` only ever touches samples
-// q = tid (mod WG), whose position inside any frame is also tid (mod WG): its N / WG
-// window taps and its hop / WG envelope values live in registers.  Every output sample
-// receives its frames in ascending order with the arithmetic of ola_kernel
-// (fma(w, x, sum), fma(w, w, wsum), sum / max(wsum, 1e-8) * scale), so the result equals
-// the two-kernel path bit for bit.
-template <class C, int WG, int ITERS>
-__global__ __launch_bounds__(WG) void istft_kernel(InvParams p) {
-  constexpr int N = C::N, HOP = N / 4;
-  constexpr int G = C::template groups<WG>();
-  constexpr int FT = G * ITERS;
-  constexpr int NW = N / WG;        // window taps per thread
-  constexpr int HW = HOP / WG;      // envelope values per thread
-  constexpr int SPAN = FT * HOP;    // samples a tile completes
-  constexpr int RING = SPAN + N;    // accumulator length
-  constexpr int QW = (G - 1) * HW + NW;  // accumulator slots per thread and iteration
-  static_assert(HOP % WG == 0 && HW >= 1, "hop must be a multiple of the workgroup size");
+// Fused istft for hop = n_fft / 4: inverse FFT + windowed overlap-add + normalisation by the
+// window envelope, no frame workspace.  A persistent workgroup (= one frame's T threads) walks
+// a contiguous run of FT-frame tiles; within a row it carries the n_fft - hop samples that
+// later frames still add to in an LDS ring, and when it starts in the middle of a row it first
+// re-transforms (without storing) the tile whose frames reach into its run.
+// In the last pass thread t receives the sample pairs n = t + T c, c = 0 .. M / T - 1, of EVERY
+// frame, and hop is a multiple of 2 T, so in the overlap ring those are always the same slots
+// (q = 2 t, 2 t + 1 mod 2 T): a thread owns its slots.  It therefore adds its outputs to the
+// ring straight from registers - no frame buffer round trip and no workgroup barrier around the
+// accumulation - normalises and stores them itself (8-byte stores, 512 B per wave), and the
+// next frame's bins are fetched as soon as pass 0 has consumed this frame's.  Arithmetic and
+// its order equal ola_kernel's (fma(w, x, sum) over ascending frames, fma(w, w, wsum),
+// sum / max(wsum, 1e-8) * scale): the results are the same bits.
+template <class C, int FT>
+__global__ __launch_bounds__(C::T) void istft_own_kernel(InvParams p) {
+  constexpr int N = C::N, M = N / 2, HOP = N / 4, WG = C::T;
+  constexpr int NC = M / WG;          // sample pairs per thread and frame
+  constexpr int SPAN = FT * HOP;      // samples a tile completes
+  constexpr int RING = SPAN + N;      // accumulator length
+  constexpr int HC = HOP / (2 * WG);  // pairs per thread and hop
+  static_assert(HOP % (2 * WG) == 0 && HC >= 1, "hop must be a multiple of twice the workgroup size");
   static_assert(FT >= 3, "one warm-up tile must cover the three frames that reach into a run");
+  static_assert((M / C::RL) % WG == 0 && (WG % 64) == 0, "a frame is the whole workgroup");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  float2* bufs = reinterpret_cast<float2*>(smem_raw);
-  float* acc = reinterpret_cast<float*>(bufs + G * C::LBUF);
+  float2* buf = reinterpret_cast<float2*>(smem_raw);
+  float2* acc = buf + C::LBUF;  // RING / 2 sample pairs
 
-  const int tid = threadIdx.x;
-  int g, t;
-  bool active;
-  C::map(tid, g, t, active);
-  float2* buf = bufs + (active ? g : 0) * C::LBUF;
+  const int t = threadIdx.x;
   const float2* __restrict__ tw = p.tw;
-  const float* __restrict__ win = p.win;
+  const float2* __restrict__ win2 = reinterpret_cast<const float2*>(p.win);
 
   const long long total = p.B * p.tiles;
   const long long first = (long long)blockIdx.x * p.tiles_per_wg;
   const long long last = first + p.tiles_per_wg < total ? first + p.tiles_per_wg : total;
   if (first >= last) return;
 
-  float wreg[NW];  // win[tid + j WG]
+  float2 wreg[NC];  // window taps of the thread's pairs
 #pragma unroll
-  for (int j = 0; j < NW; ++j) wreg[j] = win[tid + j * WG];
-  // envelope of a sample whose four frames all exist: sum of w^2 over s = r + c hop,
-  // c = 3..0 (ascending frames = descending position in the frame), r = tid + m WG
-  float wsq[HW];
+  for (int c = 0; c < NC; ++c) wreg[c] = win2[t + c * WG];
+  // envelope of a sample whose four frames all exist: sum of w^2 over positions r + c hop,
+  // c = 3..0 (ascending frames = descending position in the frame)
+  float2 wsq[HC];
 #pragma unroll
-  for (int m = 0; m < HW; ++m) {
-    float ws = 0.0f;
+  for (int m = 0; m < HC; ++m) {
+    float2 ws = {0.0f, 0.0f};
 #pragma unroll
-    for (int c = 3; c >= 0; --c) ws = fmaf(wreg[m + c * HW], wreg[m + c * HW], ws);
+    for (int c = 3; c >= 0; --c) {
+      const float2 w = wreg[m + c * HC];
+      ws = {fmaf(w.x, w.x, ws.x), fmaf(w.y, w.y, ws.y)};
+    }
     wsq[m] = ws;
   }
 
-  // one warm-up tile when the run starts in the middle of a row
-  long long idx = (first % p.tiles) > 0 ? first - 1 : first;
-  // The accumulator is a ring: `origin` is the slot of the tile's first sample; a slot
-  // is cleared when its sample is stored, which makes it the far end of the ring.
-  for (int q = tid; q < RING; q += WG) acc[q] = 0.0f;
-  int origin = 0;
+  long long idx = (first % p.tiles) > 0 ? first - 1 : first;  // one warm-up tile inside a row
+  for (int q = t; q < RING / 2; q += WG) acc[q] = {0.0f, 0.0f};
+  int origin = 0;  // ring slot (in pairs) of the tile's first sample
   auto slot = [&](int q) {
-    const int s = origin + q;
-    return s >= RING ? s - RING : s;
+    const int s2 = origin + q;
+    return s2 >= RING / 2 ? s2 - RING / 2 : s2;
   };
   __syncthreads();
 
+  FrameTwiddles<C> rt;
+  rt.load(tw, t);
   FrameBins<C> fb;
+  fb.ready = false;
   for (; idx < last; ++idx) {
     const long long b = idx / p.tiles;
     const int tile = (int)(idx - b * p.tiles);
     const long long f0 = (long long)tile * FT;
     const int nf = p.F - f0 < FT ? (int)(p.F - f0) : FT;  // frames of this tile that exist
-#pragma unroll
-    for (int it = 0; it < ITERS; ++it) {
-      // ---- every group transforms one frame into its own buffer ------------------------
-      if (active) {
-        const bool valid = it * G + g < nf;
-        if (C::MULTIWAVE || valid) {
-          const float2* __restrict__ xs = p.spec + b * p.sb + (valid ? f0 + it * G + g : 0) * p.sf;
-          // (no prefetch of the next frame's bins: with the window taps resident it would
-          // take the kernel past 256 VGPRs)
-          fb.ready = false;
-          inverse_frame<C, true>(p, tw, buf, xs, valid, t, fb, nullptr, false, [](int, float2) {});
-        } else {
-          fb.ready = false;
-        }
+    const float2* __restrict__ xrow = p.spec + b * p.sb;
+#pragma unroll 1
+    for (int it = 0; it < FT; ++it) {
+      const bool valid = it < nf;
+      const float2* __restrict__ xs = xrow + (valid ? f0 + it : 0) * p.sf;
+      // the frame after this one (same tile or the next tile of the run), for the prefetch
+      const float2* xs_next = nullptr;
+      bool valid_next = false;
+      if (it + 1 < FT) {
+        valid_next = it + 1 < nf;
+        xs_next = xrow + (valid_next ? f0 + it + 1 : 0) * p.sf;
+      } else if (idx + 1 < last) {
+        const long long bn = (idx + 1) / p.tiles;
+        const long long fn = ((idx + 1) - bn * p.tiles) * FT;
+        valid_next = true;  // the first frame of a tile always exists
+        xs_next = p.spec + bn * p.sb + fn * p.sf;
       }
-      __syncthreads();  // also orders the previous tile's clearing stores before the adds below
-      // ---- add the G frames to the accumulator, earliest frame first -------------------
-#pragma unroll
-      for (int k = 0; k < QW; ++k) {
-        const int a = slot(it * G * HOP + tid + k * WG);
-        float sum = acc[a];
-#pragma unroll
-        for (int gg = 0; gg < G; ++gg) {
-          const int j = k - gg * HW;  // the sample is tap tid + j WG of frame gg
-          if (j >= 0 && j < NW && it * G + gg < nf) {
-            const float* __restrict__ fr = reinterpret_cast<const float*>(bufs + gg * C::LBUF);
-            sum = fmaf(wreg[j], fr[tid + j * WG], sum);
-          }
-        }
-        acc[a] = sum;
-      }
-      __syncthreads();
+      const int qf = it * (HOP / 2) + t;  // pair index of the thread's first pair of this frame
+      inverse_frame<C, false, true>(
+          p, tw, buf, xs, valid, t, fb, xs_next, valid_next,
+          [&](int, float2 v, int c) {
+            if (valid) {
+              const int a = slot(qf + c * WG);
+              const float2 sum = acc[a];
+              acc[a] = {fmaf(wreg[c].x, v.x, sum.x), fmaf(wreg[c].y, v.y, sum.y)};
+            }
+          },
+          &rt);
     }
-    // ---- the first SPAN samples are complete (all of them at the end of a row):
-    // normalise, store, clear ---------------------------------------------------------------
+    // ---- the first SPAN samples are complete (all of them at the end of a row) ------------
     const long long base = f0 * HOP;  // output position of the tile's first sample
     const bool row_end = tile == p.tiles - 1;
     const long long left = p.out_len - base;  // samples of the row from `base` on
     float* __restrict__ orow = p.out + b * p.out_len + base;
-    if (!row_end && f0 >= 3 && nf == FT && left >= SPAN) {
-      // every sample of the span has its four frames: envelope from registers
+    const bool aligned8 = (reinterpret_cast<uintptr_t>(orow) & 7) == 0;
+    if (!row_end && f0 >= 3 && nf == FT && left >= SPAN && aligned8) {
+      // every sample of the span has its four frames: the thread's own pairs, envelope from registers
 #pragma unroll
-      for (int k = 0; k < SPAN / WG; ++k) {
-        const int a = slot(tid + k * WG);
-        const float sum = acc[a];
-        acc[a] = 0.0f;
-        if (idx >= first) orow[tid + k * WG] = sum / fmaxf(wsq[k % HW], 1e-8f) * p.scale;
+      for (int k = 0; k < SPAN / (2 * WG); ++k) {
+        const int a = slot(t + k * WG);
+        const float2 sum = acc[a];
+        acc[a] = {0.0f, 0.0f};
+        if (idx >= first) {
+          const float2 ws = wsq[k % HC];
+          reinterpret_cast<float2*>(orow)[t + k * WG] = {sum.x / fmaxf(ws.x, 1e-8f) * p.scale,
+                                                         sum.y / fmaxf(ws.y, 1e-8f) * p.scale};
+        }
       }
     } else {
+      // row ends and the first tile of a row: any thread takes any sample
+      __syncthreads();
+      float* __restrict__ accf = reinterpret_cast<float*>(acc);
       const int avail = row_end ? RING : SPAN;
       const int count = left < avail ? (left < 0 ? 0 : (int)left) : avail;
-      for (int q = tid; q < avail; q += WG) {
-        const int a = slot(q);
-        const float sum = acc[a];
-        acc[a] = 0.0f;
+      for (int q = t; q < avail; q += WG) {
+        int a = 2 * origin + q;
+        a = a >= RING ? a - RING : a;
+        const float sum = accf[a];
+        accf[a] = 0.0f;
         if (q < count && idx >= first) {
           // frames f0 + fa .. f0 + fb contain this sample (relative to the tile, may be < 0)
           int fa = q - N + 1;
@@ -452,21 +550,22 @@ __global__ __launch_bounds__(WG) void istft_kernel(InvParams p) {
           if (f0 + fbx > p.F - 1) fbx = (int)(p.F - 1 - f0);
           float wsum = 0.0f;
           for (int f = fa; f <= fbx; ++f) {
-            const float w = win[q - f * HOP];
+            const float w = p.win[q - f * HOP];
             wsum = fmaf(w, w, wsum);
           }
           orow[q] = sum / fmaxf(wsum, 1e-8f) * p.scale;
         }
       }
+      if (row_end && idx >= first) {  // anything past the accumulator is beyond the last frame: zeros
+        for (long long i = base + RING + t; i < p.out_len; i += WG) p.out[b * p.out_len + i] = 0.0f;
+      }
+      __syncthreads();
     }
     if (row_end) {
-      // anything past the accumulator is beyond the last frame: zeros
-      if (idx >= first) {
-        for (long long i = base + RING + tid; i < p.out_len; i += WG) p.out[b * p.out_len + i] = 0.0f;
-      }
       origin = 0;
+      fb.ready = fb.ready && idx + 1 < last;  // (the prefetched frame is the next row's first: still right)
     } else {
-      origin = slot(SPAN);
+      origin = slot(SPAN / 2);
     }
   }
 }
@@ -476,19 +575,15 @@ using Inv256 = InvCfg<256, 8, 8, 16, 1, 8>;
 using Inv400 = InvCfg<400, 10, 10, 20, 1, 10>;
 using Inv512 = InvCfg<512, 32, 4, 8, 8, 4>;
 using Inv800 = InvCfg<800, 10, 20, 20, 1, 20>;
-using Inv1024 = InvCfg<1024, 32, 8, 8, 8, 8>;
-using Inv2048 = InvCfg<2048, 64, 8, 8, 16, 8>;
-#ifndef MIA_INV4096_V2
-#define MIA_INV4096_V2 0
-#endif
-#if MIA_INV4096_V2
-// eight points per thread and pass, a frame is four whole waves (see Cfg4096 of the forward kernel)
+// 1024 / 2048 / 4096 points: eight points per thread and pass (four passes of radix 4 / 8), a
+// frame is one, two or four whole waves = the whole workgroup of the fused kernel
+// (istft_own_kernel), twiddles resident in registers.  Measured on the HTDemucs round trip
+// (128 rows x 180 s) against the three-pass plan <4096, 128, 8, 16, 16> with table twiddles and
+// two frames per workgroup: inverse 9.9 -> 5.3 ms.  The table loads in front of
+// every pass were the difference: the same four-pass plan with table twiddles took 11.2 ms.
+using Inv1024 = InvCfg<1024, 64, 4, 8, 4, 8, 4>;
+using Inv2048 = InvCfg<2048, 128, 4, 8, 8, 8, 4>;
 using Inv4096 = InvCfg<4096, 256, 4, 8, 8, 8, 8>;
-constexpr int kInv4096Iters = 4, kInv4096FusedIters = 4;
-#else
-using Inv4096 = InvCfg<4096, 128, 8, 16, 16, 8>;
-constexpr int kInv4096Iters = 4, kInv4096FusedIters = 2;
-#endif
 
 template <class C, int WG, int ITERS>
 static int launch_inv(const InvParams& p0, hipStream_t s) {
@@ -514,17 +609,15 @@ static int launch_inv(const InvParams& p0, hipStream_t s) {
   return MIA_OK;
 }
 
-template <class C, int WG, int ITERS>
-static int launch_fused(const InvParams& p0, hipStream_t s) {
-  constexpr int G = C::template groups<WG>();
-  constexpr int FT = G * ITERS;
+template <class C, int FT>
+static int launch_fused_own(const InvParams& p0, hipStream_t s) {
+  constexpr int WG = C::T;
   InvParams p = p0;
   p.tiles = (int)((p.F + FT - 1) / FT);
   const long long total = p.B * p.tiles;
   if (total <= 0) return MIA_OK;
-  constexpr size_t lds = sizeof(float2) * G * C::LBUF + sizeof(float) * ((size_t)FT * (C::N / 4) + C::N);
-  static_assert(lds <= 80 * 1024, "two workgroups per CU");
-  auto kern = istft_kernel<C, WG, ITERS>;
+  constexpr size_t lds = sizeof(float2) * C::LBUF + sizeof(float) * ((size_t)FT * (C::N / 4) + C::N);
+  auto kern = istft_own_kernel<C, FT>;
   if (lds > 64 * 1024) {
     MIA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -557,9 +650,9 @@ bool istft_fused_supported(int n_fft, int hop) {
 
 int launch_istft_fused(const mia_plan* plan, const InvParams& p, hipStream_t s) {
   switch (plan->n_fft) {
-    case 1024: return launch_fused<Inv1024, 256, 2>(p, s);
-    case 2048: return launch_fused<Inv2048, 256, 2>(p, s);
-    case 4096: return launch_fused<Inv4096, 256, kInv4096FusedIters>(p, s);
+    case 1024: return launch_fused_own<Inv1024, 4>(p, s);
+    case 2048: return launch_fused_own<Inv2048, 4>(p, s);
+    case 4096: return launch_fused_own<Inv4096, 4>(p, s);
     default:
       set_error("n_fft=%d has no fused inverse", plan->n_fft);
       return MIA_ERR_UNSUPPORTED;
@@ -574,7 +667,7 @@ int launch_inverse(const mia_plan* plan, const InvParams& p, hipStream_t s) {
     case 800: return launch_inv<Inv800, 128, 4>(p, s);
     case 1024: return launch_inv<Inv1024, 256, 4>(p, s);
     case 2048: return launch_inv<Inv2048, 256, 4>(p, s);
-    case 4096: return launch_inv<Inv4096, 256, kInv4096Iters>(p, s);
+    case 4096: return launch_inv<Inv4096, 256, 4>(p, s);
     default:
       set_error("n_fft=%d has no compiled FFT plan", plan->n_fft);
       return MIA_ERR_UNSUPPORTED;

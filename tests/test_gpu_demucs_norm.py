@@ -56,11 +56,11 @@ def test_contiguous_spectrogram_odd_tile_sizes_and_c_abi(gpu):
     s = torch.cuda.current_stream(gpu).cuda_stream
     assert lib.mia_normalize_rows(x.data_ptr(), 1, 0, 1e-5, x.data_ptr(), x.data_ptr(), sums.data_ptr(), s) == _lib.MIA_ERR_INVALID
     # more rows than one launch's grid takes: the entry point goes through them in pieces
-    big = torch.randn((70000, 3), device=gpu)
+    big = torch.randn((70000, 16), device=gpu, generator=torch.Generator(device=gpu).manual_seed(11))
     big_out = torch.empty_like(big)
     big_st = torch.empty((70000, 2), device=gpu)
     big_sums = torch.zeros((70000, 2), dtype=torch.float64, device=gpu)
-    assert lib.mia_normalize_rows(big.data_ptr(), 70000, 3, 1e-5, big_out.data_ptr(), big_st.data_ptr(),
+    assert lib.mia_normalize_rows(big.data_ptr(), 70000, 16, 1e-5, big_out.data_ptr(), big_st.data_ptr(),
                                   big_sums.data_ptr(), s) == _lib.MIA_OK
     torch.cuda.synchronize()
     mean = big.double().mean(dim=1)
