@@ -11,7 +11,7 @@ for w in clap64 mfcc40 htdemucs; do
   bash tools/profile_workload.sh $w r02 2>/dev/null | grep "mia::" | cut -c1-200 >> "$rep" || exit 1
   bash tools/traffic_workload.sh $w 2>/dev/null | grep -v amdgpu.ids >> "$rep" || exit 1
 done
-for spec in "clap64 fwd_kernel" "mfcc40 fwd_kernel" "htdemucs fwd_kernel" "htdemucs istft_kernel"; do
+for spec in "clap64 fwd_kernel" "mfcc40 fwd_kernel" "htdemucs fwd_kernel" "htdemucs istft_own_kernel"; do
   set -- $spec
   echo "== SQ counters: $1, kernels matching $2 (mean per launch; *_CYCLES / ACTIVE / WAIT tick once per 4 clocks)" >> "$rep"
   bash tools/pmc_w.sh $1 $2 r02_$2 2>/dev/null | grep -v amdgpu.ids >> "$rep" || exit 1
