@@ -195,12 +195,12 @@ KERNEL_OF = {
     "whisper128": "logmel400d_kernel (fused pad+frame+window+rFFT-400+128-mel+log10; LDS-DMA staging, compiled mel sweep, line-aligned stores)",
     "clap64": "fwd_kernel<1024, mel> (fused pad+frame+window+rFFT+mel+dB)",
     "mfcc40": "fwd_kernel<2048, mel> (fused rFFT+mel+dB) followed by dct2_mfma_kernel",
-    "htdemucs": "fwd_kernel<4096> then istft_kernel<4096> (fused inverse FFT + overlap-add)",
+    "htdemucs": "fwd_kernel<4096> then istft_own_kernel<4096> (fused inverse FFT + overlap-add)",
     "resample": "upfirdn_kernel (polyphase FIR, input span and phase table staged in LDS)",
     "contrast": "spectral_contrast_kernel<16> (one thread per frame, sorted register arrays)",
     "demucs_front": "fwd_kernel<4096> + cac_moments_kernel + cac_normalize_kernel + row kernels",
-    "spectral_gate": "fwd_kernel<2048> + magnitude/phase + 9 mask kernels + polar + istft_kernel<2048>",
-    "griffinlim": "per iteration istft_kernel<2048> + fwd_kernel<2048> + griffinlim_update_kernel",
+    "spectral_gate": "fwd_kernel<2048> + magnitude/phase + 9 mask kernels + polar + istft_own_kernel<2048>",
+    "griffinlim": "per iteration istft_own_kernel<2048> + fwd_kernel<2048> + griffinlim_update_kernel",
     "onset": "onset_flux_shift_kernel (a wave per 64 frames, lagged values by lane shift)",
     "features_y": "fwd_kernel<2048> with the statistics epilogue (no spectrogram in memory)",
     "features_all": "spectral_stat_kernel, all four statistics in two passes over the bins",
