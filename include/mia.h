@@ -99,7 +99,9 @@ int mia_plan_destroy(mia_plan* plan);
  * registers instead of LDS-DMA loads and takes the Cooley-Tukey split of the transform;
  * results agree to float32 round-off), "w400_mfma_mel" (1: the register-staging kernel
  * projects onto the mel bank with v_mfma_f32_16x16x4_f32 over 16-filter bands instead of
- * sweeping; slower, kept for A/B measurements; needs n_mels <= 128).  Info keys: "w400_bank"
+ * sweeping; slower, kept for A/B measurements; needs n_mels <= 128), "w400_dpp_pass2" (1: the
+ * LDS-DMA kernel runs the radix-16 pass of its transform across the lanes with DPP operands
+ * instead of exchanging through LDS; slower, kept for A/B measurements).  Info keys: "w400_bank"
  * (80 / 128 when the compiled sweep applies, else 0), "w400_tables" (1 when the n_fft = 400
  * kernel serves the plan), "w400_mfma_tables" (1 when the matrix-core mode is available),
  * "compute_units".  Not thread-safe against launches that use the plan. */

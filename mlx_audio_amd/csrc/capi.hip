@@ -563,6 +563,10 @@ int mia_plan_set_option(mia_plan* plan, const char* key, int value) {
     plan->opt_mfma_mel = value != 0;
     return MIA_OK;
   }
+  if (strcmp(key, "w400_dpp_pass2") == 0) {
+    plan->opt_dpp_pass2 = value != 0;
+    return MIA_OK;
+  }
   set_error("unknown plan option '%s'", key);
   return MIA_ERR_INVALID;
 }
@@ -793,7 +797,7 @@ static int forward_mel_dispatch(const mia_plan* plan, const FwdParams& p, hipStr
   if (plan->d_sweep_meta != nullptr && p.n_mels * p.F < (1LL << 30)) {
     W400Tables tb{plan->d_win16, plan->d_tw16, plan->d_winp, plan->d_sweep_meta, plan->d_sweep_w,
                   plan->w400_bank, plan->opt_table_sweep, plan->opt_vgpr_staging, plan->cus,
-                  plan->d_mfma_meta, plan->d_mfma_a, plan->opt_mfma_mel};
+                  plan->d_mfma_meta, plan->d_mfma_a, plan->opt_mfma_mel, plan->opt_dpp_pass2};
     return launch_logmel400(p, tb, s);
   }
   return launch_forward(plan, p, 1, s);

@@ -740,6 +740,74 @@ struct SweepCtxDma {
   }
 };
 
+// ---- pass 2 across the lanes (P2 = 1 of logmel400d_kernel; kept for A/B measurements) -------
+// The 16 roles of a frame are the 16 lanes of one DPP row, so the radix-16 transform over the
+// roles can run as four radix-2 decimation-in-frequency stages whose partner operand comes
+// through the DPP crossbar instead of an exchange through LDS: lane n and lane n ^ h
+// (h = 8, 4, 2, 1) form (own + partner) in the lane with bit h clear and
+// (partner - own) * W_{2h}^(n mod h) in the other.  After the four stages lane n holds output
+// k1 = bit-reversed n.  Per complex value: 4 instructions per stage + 4 per twiddle layer
+// (three layers) = 28, against 10 for the register-resident Dft<16> (160 / 16): the form costs
+// more arithmetic than the exchange it removes (see the A/B in the profiles directory).
+// lanes n and n ^ 4: no single DPP pattern swaps banks of four lanes, so the lanes with bit 2
+// clear take lane n + 4 (row_ror:12, banks 0 and 2) and add, the others take lane n - 4
+// (row_ror:4, banks 1 and 3) and subtract.  (s_nop: a DPP read of a register the previous
+// vector instruction wrote needs two wait states, which the compiler does not see here.)
+__device__ __forceinline__ float2 dpp_bfly4(float2 y) {
+  float2 t;
+  asm("s_nop 1\n\t"
+      "v_add_f32_dpp %0, %2, %2 row_ror:12 row_mask:0xf bank_mask:0x5\n\t"
+      "v_sub_f32_dpp %0, %2, %2 row_ror:4 row_mask:0xf bank_mask:0xa\n\t"
+      "v_add_f32_dpp %1, %3, %3 row_ror:12 row_mask:0xf bank_mask:0x5\n\t"
+      "v_sub_f32_dpp %1, %3, %3 row_ror:4 row_mask:0xf bank_mask:0xa"
+      : "=&v"(t.x), "=&v"(t.y)
+      : "v"(y.x), "v"(y.y));
+  return t;
+}
+// partner + sgn * own for the lane pairs of one DPP pattern (sgn = +1 / -1 per lane).  Written
+// as v_add_f32_dpp by hand: the compiler leaves a v_mov_b32_dpp in front of every addition.
+#define MIA_DPP_BFLY(NAME, PATTERN)                                                        \
+  __device__ __forceinline__ float2 NAME(float2 y, float sgn) {                            \
+    const float zx = sgn * y.x, zy = sgn * y.y;                                            \
+    float2 t;                                                                              \
+    asm("s_nop 1\n\t"                                                                      \
+        "v_add_f32_dpp %0, %2, %4 " PATTERN " row_mask:0xf bank_mask:0xf\n\t"              \
+        "v_add_f32_dpp %1, %3, %5 " PATTERN " row_mask:0xf bank_mask:0xf"                  \
+        : "=&v"(t.x), "=&v"(t.y)                                                           \
+        : "v"(y.x), "v"(y.y), "v"(zx), "v"(zy));                                           \
+    return t;                                                                              \
+  }
+MIA_DPP_BFLY(dpp_bfly8, "row_ror:8")               // lane ^ 8
+MIA_DPP_BFLY(dpp_bfly2, "quad_perm:[2,3,0,1]")     // lane ^ 2
+MIA_DPP_BFLY(dpp_bfly1, "quad_perm:[1,0,3,2]")     // lane ^ 1
+#undef MIA_DPP_BFLY
+struct DppTwiddles {
+  float2 w8, w4, w2;  // the lane's stage twiddles (1 in the lanes that add)
+  float s8, s2, s1;   // -1 in the lanes that subtract
+};
+__device__ __forceinline__ DppTwiddles dpp_twiddles(int n) {  // n = role = lane of the row
+  DppTwiddles t;
+  auto w = [](int k, int N, bool on) -> float2 {  // exp(-2 pi i k / N) or 1
+    float s, c;
+    sincospif(-2.0f * (float)k / (float)N, &s, &c);
+    return on ? float2{c, s} : float2{1.0f, 0.0f};
+  };
+  t.w8 = w(n & 7, 16, (n & 8) != 0);
+  t.w4 = w(n & 3, 8, (n & 4) != 0);
+  t.w2 = w(n & 1, 4, (n & 2) != 0);
+  t.s8 = (n & 8) ? -1.0f : 1.0f;
+  t.s2 = (n & 2) ? -1.0f : 1.0f;
+  t.s1 = (n & 1) ? -1.0f : 1.0f;
+  return t;
+}
+// X[bitrev4(lane), .] of the row's 16 values y
+__device__ __forceinline__ float2 dpp_dft16(float2 y, const DppTwiddles& t) {
+  y = cmul(dpp_bfly8(y, t.s8), t.w8);
+  y = cmul(dpp_bfly4(y), t.w4);
+  y = cmul(dpp_bfly2(y, t.s2), t.w2);
+  return dpp_bfly1(y, t.s1);
+}
+
 // Issue the loads of the wave's 880 samples starting at sample s_wave of clip row yb.
 __device__ __forceinline__ void dma_wave_samples(const float* __restrict__ yb, long long T,
                                                  long long s_wave, int pad_mode, int lane,
@@ -771,7 +839,7 @@ __device__ __forceinline__ void dma_wave_samples(const float* __restrict__ yb, l
   }
 }
 
-template <int EPI, int BANK>
+template <int EPI, int BANK, int P2>
 __global__ __launch_bounds__(w400d::WG, 4) void logmel400d_kernel(
     FwdParams p, const float* __restrict__ g_y, const float* __restrict__ g_win,
     float* __restrict__ g_out, int* __restrict__ g_maxkey, int* __restrict__ g_minkey) {
@@ -807,6 +875,11 @@ __global__ __launch_bounds__(w400d::WG, 4) void logmel400d_kernel(
   for (int r = 0; r < 25; ++r) asm volatile("" : "+v"(wnd[r]), "+v"(sadr[r]));
 #pragma unroll
   for (int i = 0; i < NDMA; ++i) asm volatile("" : "+v"(soff[i]));
+  DppTwiddles dtw = dpp_twiddles(role0);  // (P2 = 1) stage twiddles of the cross-lane pass 2
+  if (P2 == 1) {
+    asm volatile("" : "+v"(dtw.w8.x), "+v"(dtw.w8.y), "+v"(dtw.w4.x), "+v"(dtw.w4.y), "+v"(dtw.w2.x),
+                 "+v"(dtw.w2.y), "+v"(dtw.s8), "+v"(dtw.s2), "+v"(dtw.s1));
+  }
 
   int cur_b = first / p.tiles;
   int cur_tile = first - cur_b * p.tiles;
@@ -889,6 +962,7 @@ __global__ __launch_bounds__(w400d::WG, 4) void logmel400d_kernel(
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     // ---- pass 1: windowed real radix-25 over this role's samples: Y[k2], k2 = 0..12 ---------
+    float pw[16];
     {
       float2 y[13];
       float x[25];
@@ -921,13 +995,22 @@ __global__ __launch_bounds__(w400d::WG, 4) void logmel400d_kernel(
           }
         }
       }
-      float2* __restrict__ exw = reinterpret_cast<float2*>(exf + 26 * role);
-      if (!MIA_DBG(p, 64)) {  // (ablation bit 64: no exchange)
+      if constexpr (P2 == 1) {
+        // ---- pass 2 across the lanes: this lane ends up with X[k1 = bitrev(role), k2 = c] ----
 #pragma unroll
-        for (int c = 0; c < 13; ++c) exw[c] = y[c];
+        for (int c = 0; c < 13; ++c) {
+          const float2 v = dpp_dft16(y[c], dtw);
+          pw[c] = fmaf(v.x, v.x, v.y * v.y);
+        }
       } else {
+        float2* __restrict__ exw = reinterpret_cast<float2*>(exf + 26 * role);
+        if (!MIA_DBG(p, 64)) {  // (ablation bit 64: no exchange)
 #pragma unroll
-        for (int c = 0; c < 13; ++c) asm volatile("" ::"v"(y[c].x), "v"(y[c].y));
+          for (int c = 0; c < 13; ++c) exw[c] = y[c];
+        } else {
+#pragma unroll
+          for (int c = 0; c < 13; ++c) asm volatile("" ::"v"(y[c].x), "v"(y[c].y));
+        }
       }
     }
     STAMP(2)
@@ -936,8 +1019,7 @@ __global__ __launch_bounds__(w400d::WG, 4) void logmel400d_kernel(
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 
     // ---- pass 2: butterfly k2 = role (0..12): radix-16 over the roles n1; v[k1] = X[k1, k2] ----
-    float pw[16];
-    {
+    if constexpr (P2 == 0) {
       float2 v[16];
       const int k1r = role < 13 ? role : 12;
       const float2* __restrict__ exr = reinterpret_cast<const float2*>(exf + 2 * k1r);
@@ -955,7 +1037,7 @@ __global__ __launch_bounds__(w400d::WG, 4) void logmel400d_kernel(
     // opaque: the exchange has been read back (the power values depend on it) before
     // anything below is issued
 #pragma unroll
-    for (int k2 = 0; k2 < 16; ++k2) asm volatile("" : "+v"(pw[k2]));
+    for (int k2 = 0; k2 < (P2 == 1 ? 13 : 16); ++k2) asm volatile("" : "+v"(pw[k2]));
 
     STAMP(3)
     // ---- the next tile's samples: the staging area is free from here on ------------------
@@ -966,7 +1048,12 @@ __global__ __launch_bounds__(w400d::WG, 4) void logmel400d_kernel(
 
     STAMP(4)
     // ---- power columns of the wave's 4 frames: X[k1, k2] at slot[4 (13 k1 + k2) + fi] --------
-    if (role < 13 && !MIA_DBG(p, 256)) {  // (ablation bit 256: no power write)
+    if constexpr (P2 == 1) {
+      const int k1 = (int)(__builtin_bitreverse32((unsigned)role) >> 28);
+      float* __restrict__ pa = slot + 4 * 13 * k1 + fi;
+#pragma unroll
+      for (int c = 0; c < 13; ++c) pa[4 * c] = pw[c];
+    } else if (role < 13 && !MIA_DBG(p, 256)) {  // (ablation bit 256: no power write)
       float* __restrict__ pa = slot + 4 * role + fi;
 #pragma unroll
       for (int k1 = 0; k1 < 16; ++k1) pa[4 * 13 * k1] = pw[k1];
@@ -1097,8 +1184,13 @@ int w400_compiled_bank(const float* basis, int n_mels, int bins) {
 
 template <int EPI, int BANK>
 static void launch_w400d(const FwdParams& p, const W400Tables& tb, unsigned grid, hipStream_t s) {
-  hipLaunchKernelGGL((logmel400d_kernel<EPI, BANK>), dim3(grid), dim3(w400d::WG), 0, s, p, p.y,
-                     tb.winp, p.mout, p.clip_max_key, p.clip_min_key);
+  if (tb.force_dpp_pass2) {
+    hipLaunchKernelGGL((logmel400d_kernel<EPI, BANK, 1>), dim3(grid), dim3(w400d::WG), 0, s, p, p.y,
+                       tb.winp, p.mout, p.clip_max_key, p.clip_min_key);
+  } else {
+    hipLaunchKernelGGL((logmel400d_kernel<EPI, BANK, 0>), dim3(grid), dim3(w400d::WG), 0, s, p, p.y,
+                       tb.winp, p.mout, p.clip_max_key, p.clip_min_key);
+  }
 }
 
 template <int EPI, int BANK>

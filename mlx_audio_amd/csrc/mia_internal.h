@@ -106,6 +106,7 @@ struct mia_plan {
   int opt_table_sweep = 0;       // mia_plan_set_option("w400_table_sweep"): ablation / test knob
   int opt_vgpr_staging = 0;      // mia_plan_set_option("w400_vgpr_staging"): ablation / test knob
   int opt_mfma_mel = 0;          // mia_plan_set_option("w400_mfma_mel"): A/B knob, matrix-core projection
+  int opt_dpp_pass2 = 0;         // mia_plan_set_option("w400_dpp_pass2"): A/B knob, cross-lane (DPP) radix-16 pass
   int* d_mfma_meta = nullptr;    // tables of that projection (n_mels <= 128)
   float* d_mfma_a = nullptr;
 };
@@ -161,6 +162,7 @@ struct W400Tables {
   const int* mfma_meta;   // matrix-core projection: [4 groups][2 blocks]{block, first bin, steps, A offset}
   const float* mfma_a;    // ... its A operands, [step][lane], zero-padded; null: filterbank not eligible
   int force_mfma;         // testing / A-B: project on the matrix cores instead of sweeping
+  int force_dpp_pass2;    // testing / A-B: LDS-DMA kernel with the radix-16 pass across the lanes (DPP)
 };
 
 struct InvParams {

@@ -156,3 +156,44 @@ def test_nan_and_inf_clips_matrix_core_projection():
         lib.mia_plan_set_option(plan.handle, b"w400_table_sweep", 0)
     assert np.allclose(got, want, rtol=0, atol=2e-6, equal_nan=True)
     assert np.isnan(got[1]).all() and np.isnan(got[2]).all() and np.isfinite(got[0]).all()
+
+
+@pytest.mark.parametrize("n_mels", [80, 128])
+@pytest.mark.parametrize("shape", [(3, 480000), (5, 16000), (2, 10240), (300, 4000)])
+def test_cross_lane_pass2_equals_lds_exchange(n_mels, shape):
+    """The A/B variant of the LDS-DMA kernel whose radix-16 pass runs across the lanes with
+    DPP operands, against the shipped form (exchange through LDS, register butterflies): the
+    same transform in another order of additions, so float32 round-off apart (each form is
+    within 2e-6 of the float64 result, hence 4e-6 between the two)."""
+    plan = _plan(n_mels)
+    lib = _lib.lib()
+    g = torch.Generator(device="cuda").manual_seed(shape[0] * 31 + n_mels)
+    y = torch.randn(shape, device="cuda", generator=g)
+    y[0, : shape[1] // 2] *= 1e-4
+    y[1] = 0.0
+    try:
+        for per_clip in (1, 0):
+            want = _logmel(plan, y, per_clip)
+            _lib.check(lib.mia_plan_set_option(plan.handle, b"w400_dpp_pass2", 1))
+            got = _logmel(plan, y, per_clip)
+            _lib.check(lib.mia_plan_set_option(plan.handle, b"w400_dpp_pass2", 0))
+            assert np.abs(got - want).max() <= 4e-6, (n_mels, shape, per_clip)
+    finally:
+        lib.mia_plan_set_option(plan.handle, b"w400_dpp_pass2", 0)
+
+
+def test_nan_and_inf_clips_cross_lane_pass2():
+    plan = _plan(128)
+    lib = _lib.lib()
+    g = torch.Generator(device="cuda").manual_seed(8)
+    y = torch.randn((4, 32000), device="cuda", generator=g)
+    y[1, 777] = float("nan")
+    y[2, 1234] = float("inf")
+    try:
+        want = _logmel(plan, y)
+        _lib.check(lib.mia_plan_set_option(plan.handle, b"w400_dpp_pass2", 1))
+        got = _logmel(plan, y)
+    finally:
+        lib.mia_plan_set_option(plan.handle, b"w400_dpp_pass2", 0)
+    assert np.allclose(got, want, rtol=0, atol=4e-6, equal_nan=True)
+    assert np.isnan(got[1]).all() and np.isnan(got[2]).all() and np.isfinite(got[0]).all()
