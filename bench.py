@@ -188,10 +188,32 @@ def make_workload(name: str, clips: int, device, seed: int):
                 clips * 30.0 / 3600.0, abytes,
                 f"centroid + bandwidth + roll-off + flatness from the waveform in one launch, "
                 f"{clips} x 30 s @16 kHz, n_fft 2048 hop 512", "spectral features (from audio) audio-hours/sec")
+    if name == "whisper_stem":
+        from mlx_audio_amd.frontends import WhisperEncoderStem, sinusoids
+
+        n_mels, n_state, frames = 128, 1280, 3000
+        mel = torch.randn((clips, n_mels, frames), generator=gen, device=device, dtype=torch.float32) * 0.5
+        w1 = torch.randn((n_state, 3, n_mels), generator=gen, device=device) / (3 * n_mels) ** 0.5
+        w2 = torch.randn((n_state, 3, n_state), generator=gen, device=device) / (3 * n_state) ** 0.5
+        b1 = 0.1 * torch.randn((n_state,), generator=gen, device=device)
+        b2 = 0.1 * torch.randn((n_state,), generator=gen, device=device)
+        stem = WhisperEncoderStem(w1, b1, w2, b2, sinusoids(frames // 2, n_state))
+        abytes = clips * (n_mels * frames * 4 + (frames // 2) * n_state * 2)
+        # multiply-adds of the two convolutions, 2 flops each
+        WORKLOAD_FLOPS[name] = 2.0 * clips * (frames * n_state * 3 * n_mels + (frames // 2) * n_state * 3 * n_state)
+        return (lambda: stem(mel), clips * 30.0 / 3600.0, abytes,
+                f"Whisper-large-v3 encoder stem (conv1 128->1280 k3 + GELU + conv2 1280->1280 k3 s2 + GELU + "
+                f"positional embedding) on {clips} log-mel spectrograms (128 x 3000), float16 operands, "
+                "float32 accumulation, float16 out", "Whisper encoder stem audio-hours/sec")
     raise SystemExit(f"unknown workload {name}")
 
 
+WORKLOAD_FLOPS: dict = {}   # workloads bound by the matrix cores: flops per step
+MFMA_F16_PEAK_TFLOPS = 2500.0  # MI355X dense f16 / bf16 matrix peak
+
 KERNEL_OF = {
+    "whisper_stem": "stem_gemm_kernel (implicit-GEMM Conv1d on v_mfma_f32_32x32x16_f16, LDS-DMA operand "
+                    "tiles, fused bias + GELU + embedding) x 2 after stem_prep_kernel",
     "whisper128": "logmel400d_kernel (fused pad+frame+window+rFFT-400+128-mel+log10; LDS-DMA staging, compiled mel sweep, line-aligned stores)",
     "clap64": "fwd_kernel<1024, mel> (fused pad+frame+window+rFFT+mel+dB)",
     "mfcc40": "fwd_kernel<2048, mel> (fused rFFT+mel+dB) followed by dct2_mfma_kernel",
@@ -379,7 +401,7 @@ def main() -> None:
               file=sys.stderr)
 
     default_clips = {"whisper128": 1024, "clap64": 1024, "mfcc40": 4096, "htdemucs": 128,
-                     "resample": 512, "resample_fft": 64, "features": 512, "contrast": 512, "onset": 4096, "griffinlim": 64, "spectral_gate": 64, "demucs_front": 16, "features_y": 512, "features_all": 512}
+                     "resample": 512, "resample_fft": 64, "features": 512, "contrast": 512, "onset": 4096, "griffinlim": 64, "spectral_gate": 64, "demucs_front": 16, "features_y": 512, "features_all": 512, "whisper_stem": 64}
     clips = args.clips or default_clips.get(args.workload, 1024)
     step, units, abytes, desc, metric = make_workload(args.workload, clips, device, 1234 + rank)
 
@@ -478,6 +500,12 @@ def main() -> None:
                 "device_ms_per_step": dev_ms,
             },
         }
+        if args.workload in WORKLOAD_FLOPS:
+            tf = WORKLOAD_FLOPS[args.workload] / (dev_ms * 1e-3) / 1e12
+            line["dtype"] = "f16 (f32 accumulate)"
+            line["roofline"].update({"bound": "mfma", "achieved": tf, "peak": MFMA_F16_PEAK_TFLOPS,
+                                     "unit": "TFLOP/s", "frac": tf / MFMA_F16_PEAK_TFLOPS,
+                                     "flops_per_step": WORKLOAD_FLOPS[args.workload]})
         if gather is not None:
             line["gather"] = gather
         if n_gpus == 1 and not args.no_cpu_baseline:

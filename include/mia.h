@@ -394,6 +394,28 @@ int mia_normalize_cac(const void* spec, int64_t batch, int channels, int64_t bin
                       int64_t stride_b, int64_t stride_c, int64_t stride_f, int64_t stride_t,
                       float eps, float* out, float* stats, void* sums, void* stream);
 
+/* ---- Whisper encoder stem (models/whisper/layers/encoder.py:72-109) ----------------------
+ * What AudioEncoder.__call__ does before its transformer blocks: x = mel^T (frames, n_mels);
+ * gelu(conv1(x)) with Conv1d(n_mels, n_state, kernel 3, padding 1); gelu(conv2(.)) with
+ * Conv1d(n_state, n_state, kernel 3, stride 2, padding 1); + positional_embedding[:frames'].
+ * GELU is the exact (erf) form of mlx.nn.gelu.  Arithmetic: float16 operands on the matrix
+ * cores with float32 accumulation, float32 bias / GELU / embedding (the precision of a
+ * float16 checkpoint; a float32 checkpoint is rounded to float16 by mia_whisper_stem_pack).
+ * conv*_w are in the reference's own layout (out_channels, kernel, in_channels), float32,
+ * device memory; `packed` (mia_whisper_stem_weight_bytes bytes, 16-byte aligned device memory)
+ * receives the float16 operand form once per model.  mel: device float32 (clips, n_mels,
+ * frames); out: device (clips, (frames - 1) / 2 + 1, n_state), float16 when out_f16 else
+ * float32; pos: device float32 (>= out frames, n_state) or NULL; workspace:
+ * mia_whisper_stem_workspace_bytes bytes of device memory.  n_state must be a multiple of 128
+ * (every Whisper size is); clips * frames < 2^31 per call. */
+size_t mia_whisper_stem_weight_bytes(int n_mels, int n_state);
+int mia_whisper_stem_pack(const float* conv1_w, const float* conv2_w, int n_mels, int n_state, void* packed,
+                          void* stream);
+size_t mia_whisper_stem_workspace_bytes(int64_t clips, int64_t frames, int n_mels, int n_state);
+int mia_whisper_stem(const float* mel, int64_t clips, int64_t frames, int n_mels, int n_state,
+                     const void* packed, const float* conv1_b, const float* conv2_b, const float* pos,
+                     void* out, int out_f16, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -124,6 +124,11 @@ SIGNATURES = {
     "mia_onset_flux": (c_int, [c_void_p, c_int64, c_int, c_int64, c_int, c_int, c_void_p, c_void_p]),
     "mia_envelope_filter": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_void_p,
                                     c_int64, c_void_p]),
+    "mia_whisper_stem_weight_bytes": (c_size_t, [c_int, c_int]),
+    "mia_whisper_stem_pack": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "mia_whisper_stem_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int, c_int]),
+    "mia_whisper_stem": (c_int, [c_void_p, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                 c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "mia_resample_fft_table_bytes": (c_size_t, [c_int64, c_int64]),
     "mia_resample_fft_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int64]),
     "mia_resample_fft_tables": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),

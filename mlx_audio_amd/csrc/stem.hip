@@ -1,0 +1,363 @@
+// Whisper encoder stem: what the model does with the log-mel spectrogram before its transformer
+// blocks (models/whisper/layers/encoder.py:72-109): Conv1d(n_mels -> n_state, k = 3, pad 1) ->
+// GELU -> Conv1d(n_state -> n_state, k = 3, stride 2, pad 1) -> GELU -> + positional embedding.
+//
+// Both convolutions run as one GEMM kernel on the matrix cores (v_mfma_f32_32x32x16_f16, float32
+// accumulation).  With the activations stored channels-last and ONE ZERO ROW in front of and
+// behind every clip, the three taps of output frame t are 3 * C_in contiguous halves starting at
+// row stride * t of the clip, so the "im2col" matrix is just an overlapping strided view of the
+// activation buffer: row m of the GEMM starts at (clip * rows + stride * t) * C_in, K = 3 * C_in,
+// and the weights in the reference's own (out, tap, in) order are the other operand as they are.
+//
+//   stem_prep_kernel   log-mel (clips, n_mels, frames) float32, frames contiguous
+//                      -> (clips, frames + 2, C_pad) float16, channels contiguous, zero rows/pad
+//   stem_gemm_kernel   tile = 128 output channels x 128 output frames x 64 of K; 4 waves, each
+//                      64 x 64 as 2 x 2 accumulators of 32 x 32; both operand tiles arrive by
+//                      LDS-DMA (global_load_lds_dwordx4) into a double buffer, XOR-swizzled on the
+//                      source address so that the ds_read_b128 fragment reads are conflict-free;
+//                      epilogue: + bias, GELU, (+ positional embedding), float16 rows staged
+//                      through LDS and stored as whole 256-byte runs (or float32 from registers).
+// The weight operand is the MFMA's A (rows = output channels), so a lane of the result holds
+// four consecutive channels of one frame: bias and embedding are float4 loads, the float16
+// result one 8-byte LDS store.
+#include "mia_internal.h"
+
+namespace mia {
+namespace stem {
+constexpr int BM = 128, BN = 128, BK = 64, WG = 256;
+constexpr int TILE_BYTES = 128 * BK * 2;        // one operand tile: 128 rows x 128 bytes
+constexpr int BUF_BYTES = 2 * TILE_BYTES;       // weights | activations
+constexpr int STAGE_PITCH = BN * 2 + 16;        // float16 output rows in LDS: 16-byte aligned, 4 m mod 32 banks
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+static_assert(BM * STAGE_PITCH <= 2 * BUF_BYTES, "the output tile fits the operand buffers");
+
+struct Gemm {
+  const _Float16* act;  // (clips, rows_in, cin): zero row, frames, zero row
+  long long rows_in;
+  int cin;              // halves per row, a multiple of 64
+  int stride;           // 1 or 2
+  int t_out;            // output frames per clip
+  int m_total;          // clips * t_out
+  const _Float16* w;    // (n, 3 * cin)
+  const float* bias;    // (n)
+  const float* pos;     // (t_out, n) or null
+  int n;                // a multiple of 128
+  void* out;            // rows of n elements
+  long long out_rows;   // rows per clip in out
+  int out_row0;         // row of a clip's first frame in out (1 when out carries the zero rows)
+};
+
+// One wave-wide LDS-DMA load: lane L's 16 bytes at gptr land at lds_byte_addr + 16 L.  The
+// compiler does not count it; the kernel waits with an explicit s_waitcnt vmcnt(0).
+__device__ __forceinline__ void dma16(const void* gptr, unsigned lds_byte_addr) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gptr), "s"(lds_byte_addr)
+      : "memory");
+}
+
+// x * Phi(x) with Phi from the complementary error function in the form
+// erfc(z) = t (a1 + t (a2 + ... a5 t)) exp(-z^2), t = 1 / (1 + p z) (absolute error 1.5e-7,
+// no cancellation in the negative tail).
+__device__ __forceinline__ float gelu(float x) {
+  const float z = __builtin_fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  float q = fmaf(t, 1.061405429f, -1.453152027f);
+  q = fmaf(t, q, 1.421413741f);
+  q = fmaf(t, q, -0.284496736f);
+  q = fmaf(t, q, 0.254829592f);
+  const float e = __builtin_amdgcn_exp2f(-1.44269504088896340736f * z * z);
+  const float half_erfc = 0.5f * t * q * e;  // Phi(-|x|)
+  return x * (x < 0.0f ? half_erfc : 1.0f - half_erfc);
+}
+}  // namespace stem
+
+template <bool OUT_F16>
+__global__ __launch_bounds__(stem::WG, 2) void stem_gemm_kernel(stem::Gemm p) {
+  using namespace stem;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUF_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  // Workgroups go to the eight XCDs in turn; consecutive LOGICAL tiles (the column tiles that
+  // share one activation tile) are given to one XCD so that its L2 serves the re-reads.
+  const unsigned nb = gridDim.x, id = blockIdx.x;
+  const unsigned q8 = nb / 8, r8 = nb % 8, xcd = id % 8;
+  const unsigned logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + id / 8;
+  const int nt = p.n / BN;
+  const int n0 = (int)(logical % (unsigned)nt) * BN;
+  const int m0 = (int)(logical / (unsigned)nt) * BM;
+  const int K = 3 * p.cin;
+
+  // ---- sources of this thread's DMA pieces: piece s = (4 wv + i) * 64 + lane of a tile is
+  // LDS slot s = row * 8 + c'; it holds the 16 bytes of chunk c = c' ^ ((row >> 1) & 7) ----
+  const _Float16* wsrc[4];
+  const _Float16* asrc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int s = (4 * wv + i) * 64 + lane;
+    const int row = s >> 3, c = (s & 7) ^ ((row >> 1) & 7);
+    wsrc[i] = p.w + ((size_t)(n0 + row) * K + 8 * c);
+    int m = m0 + row;
+    m = m < p.m_total ? m : p.m_total - 1;  // rows past the end repeat the last one; never stored
+    const int clip = m / p.t_out, t = m - clip * p.t_out;
+    asrc[i] = p.act + (((size_t)clip * p.rows_in + (size_t)p.stride * t) * p.cin + 8 * c);
+  }
+  const unsigned lds0 = (unsigned)(unsigned long long)(smem);
+  const unsigned dst0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + 4096u * wv));
+  auto issue = [&](int ks, int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dma16(wsrc[i] + ks * BK, dst0 + buf * BUF_BYTES + 1024u * i);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dma16(asrc[i] + ks * BK, dst0 + buf * BUF_BYTES + TILE_BYTES + 1024u * i);
+  };
+
+  // ---- fragment reads: lane l holds elements k = 8 (l >> 5) + j of row l & 31 -------------
+  const int wr = wv >> 1, wc = wv & 1;  // the wave's 64 channels x 64 frames of the tile
+  const int r31 = lane & 31;
+  const int e = (lane >> 5) ^ ((r31 >> 1) & 7);
+  const unsigned char* wbase = smem + (wr * 64 + r31) * 128;
+  const unsigned char* abase = smem + TILE_BYTES + (wc * 64 + r31) * 128;
+
+  f16v acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
+
+  const int nk = K / BK;
+  issue(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int ks = 0; ks < nk; ++ks) {
+    const int buf = ks & 1;
+    if (ks + 1 < nk) issue(ks + 1, buf ^ 1);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int off = buf * BUF_BYTES + (((2 * kk) ^ e) << 4);
+      h8 a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        a[i] = *reinterpret_cast<const h8*>(wbase + off + i * 32 * 128);
+        b[i] = *reinterpret_cast<const h8*>(abase + off + i * 32 * 128);
+      }
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+          acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ni], b[mi], acc[ni][mi], 0, 0, 0);
+    }
+    // the next tile has landed, and every wave is done reading this one
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  // ---- epilogue: acc[ni][mi][reg] = channel n0 + 64 wr + 32 ni + (reg & 3) + 8 (reg >> 2)
+  // + 4 (lane >> 5) of frame m0 + 64 wc + 32 mi + (lane & 31) ----------------------------------
+  const int h = lane >> 5;
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+    const int ml = wc * 64 + mi * 32 + r31;
+    const int m = m0 + ml;
+    const bool live = m < p.m_total;
+    const int mc = live ? m : p.m_total - 1;
+    const int clip = mc / p.t_out, t = mc - clip * p.t_out;
+    const float* __restrict__ prow = p.pos ? p.pos + (size_t)t * p.n : nullptr;
+    float* __restrict__ orow =
+        reinterpret_cast<float*>(p.out) + ((size_t)clip * p.out_rows + p.out_row0 + t) * p.n;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int nl = wr * 64 + ni * 32 + 8 * g + 4 * h;
+        const float4 bv = *reinterpret_cast<const float4*>(p.bias + n0 + nl);
+        float4 v = {gelu(acc[ni][mi][4 * g] + bv.x), gelu(acc[ni][mi][4 * g + 1] + bv.y),
+                    gelu(acc[ni][mi][4 * g + 2] + bv.z), gelu(acc[ni][mi][4 * g + 3] + bv.w)};
+        if (prow) {
+          const float4 pv = *reinterpret_cast<const float4*>(prow + n0 + nl);
+          v.x += pv.x, v.y += pv.y, v.z += pv.z, v.w += pv.w;
+        }
+        if (OUT_F16) {
+          const h4 hv = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+          *reinterpret_cast<h4*>(smem + ml * STAGE_PITCH + nl * 2) = hv;
+        } else if (live) {
+          *reinterpret_cast<float4*>(orow + n0 + nl) = v;
+        }
+      }
+    }
+  }
+  if (OUT_F16) {
+    __syncthreads();
+    // 128 rows x 16 pieces of 16 bytes: 16 consecutive lanes store one row's 256 bytes
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int idx = j * WG + tid;
+      const int row = idx >> 4, cp = idx & 15;
+      const int m = m0 + row;
+      if (m < p.m_total) {
+        const int clip = m / p.t_out, t = m - clip * p.t_out;
+        const uint4 v = *reinterpret_cast<const uint4*>(smem + row * STAGE_PITCH + cp * 16);
+        _Float16* __restrict__ orow =
+            reinterpret_cast<_Float16*>(p.out) + ((size_t)clip * p.out_rows + p.out_row0 + t) * p.n;
+        *reinterpret_cast<uint4*>(orow + n0 + 8 * cp) = v;
+      }
+    }
+  }
+}
+
+// log-mel (clips, C, T) float32 -> (clips, T + 2, CP) float16, channels contiguous; rows 0 and
+// T + 1 and channels >= C are zero.  grid (ceil((T + 2) / 64), clips): a workgroup writes rows
+// 64 bx .. 64 bx + 63 of the padded clip (frame = row - 1).
+__global__ __launch_bounds__(256) void stem_prep_kernel(const float* __restrict__ mel, int C, int T, int CP,
+                                                        _Float16* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char prep_raw[];
+  _Float16* tile = reinterpret_cast<_Float16*>(prep_raw);  // [64][CP + 8]
+  const int pitch = CP + 8;
+  const long long clip = blockIdx.y;
+  const int r0 = blockIdx.x * 64;
+  const int tid = threadIdx.x, tl = tid & 63;
+  const int frame = r0 + tl - 1;
+  const bool in = frame >= 0 && frame < T;
+  const float* __restrict__ src = mel + clip * (long long)C * T + (in ? frame : 0);
+  for (int c = tid >> 6; c < CP; c += 4) {
+    const float v = (in && c < C) ? src[(long long)c * T] : 0.0f;
+    tile[tl * pitch + c] = (_Float16)v;
+  }
+  __syncthreads();
+  const int pieces = CP / 8;  // 16-byte pieces per row
+  _Float16* __restrict__ dst = out + (clip * (long long)(T + 2) + r0) * CP;
+  for (int idx = tid; idx < 64 * pieces; idx += 256) {
+    const int row = idx / pieces, cp = idx - row * pieces;
+    if (r0 + row < T + 2) {
+      *reinterpret_cast<uint4*>(dst + (long long)row * CP + 8 * cp) =
+          *reinterpret_cast<const uint4*>(tile + row * pitch + 8 * cp);
+    }
+  }
+}
+
+// rows 0 and rows - 1 of every clip of a (clips, rows, n) float16 array := 0
+__global__ __launch_bounds__(256) void stem_zero_rows_kernel(_Float16* __restrict__ x, long long rows, int n) {
+  const long long clip = blockIdx.y;
+  _Float16* __restrict__ a = x + clip * rows * n;
+  _Float16* __restrict__ b = a + (rows - 1) * n;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    a[i] = (_Float16)0.0f;
+    b[i] = (_Float16)0.0f;
+  }
+}
+
+// (n, 3, c) float32 -> (n, 3, cp) float16, zero-padded channels
+__global__ __launch_bounds__(256) void stem_pack_kernel(const float* __restrict__ w, long long rows, int c,
+                                                        int cp, _Float16* __restrict__ out) {
+  const long long total = rows * cp;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long r = i / cp;
+    const int ch = (int)(i - r * cp);
+    out[i] = ch < c ? (_Float16)w[r * c + ch] : (_Float16)0.0f;
+  }
+}
+
+static int stem_cpad(int c) { return (c + 63) / 64 * 64; }
+static size_t stem_align(size_t x) { return (x + 255) & ~(size_t)255; }
+
+}  // namespace mia
+
+using namespace mia;
+
+extern "C" {
+
+size_t mia_whisper_stem_weight_bytes(int n_mels, int n_state) {
+  if (n_mels <= 0 || n_state <= 0) return 0;
+  return stem_align((size_t)n_state * 3 * stem_cpad(n_mels) * 2) + stem_align((size_t)n_state * 3 * n_state * 2);
+}
+
+int mia_whisper_stem_pack(const float* conv1_w, const float* conv2_w, int n_mels, int n_state, void* packed,
+                          void* stream) {
+  MIA_REQUIRE(conv1_w && conv2_w && packed, "null argument");
+  MIA_REQUIRE(n_mels > 0 && n_state > 0 && n_state % 128 == 0,
+              "n_state must be a positive multiple of 128 (got %d)", n_state);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int cp = stem_cpad(n_mels);
+  _Float16* w1 = static_cast<_Float16*>(packed);
+  _Float16* w2 = reinterpret_cast<_Float16*>(static_cast<unsigned char*>(packed) +
+                                             stem_align((size_t)n_state * 3 * cp * 2));
+  hipLaunchKernelGGL(stem_pack_kernel, dim3(1024), dim3(256), 0, s, conv1_w, (long long)n_state * 3, n_mels,
+                     cp, w1);
+  hipLaunchKernelGGL(stem_pack_kernel, dim3(4096), dim3(256), 0, s, conv2_w, (long long)n_state * 3, n_state,
+                     n_state, w2);
+  MIA_CHECK_HIP(hipGetLastError());
+  return MIA_OK;
+}
+
+size_t mia_whisper_stem_workspace_bytes(int64_t clips, int64_t frames, int n_mels, int n_state) {
+  if (clips <= 0 || frames <= 0 || n_mels <= 0 || n_state <= 0) return 0;
+  return stem_align((size_t)clips * (frames + 2) * stem_cpad(n_mels) * 2) +
+         stem_align((size_t)clips * (frames + 2) * n_state * 2);
+}
+
+int mia_whisper_stem(const float* mel, int64_t clips, int64_t frames, int n_mels, int n_state,
+                     const void* packed, const float* conv1_b, const float* conv2_b, const float* pos,
+                     void* out, int out_f16, void* workspace, size_t workspace_bytes, void* stream) {
+  MIA_REQUIRE(clips >= 0 && frames > 0, "bad shape");
+  if (clips == 0) return MIA_OK;
+  MIA_REQUIRE(mel && packed && conv1_b && conv2_b && out && workspace, "null argument");
+  MIA_REQUIRE(n_mels > 0 && n_state > 0 && n_state % 128 == 0,
+              "n_state must be a positive multiple of 128 (got %d)", n_state);
+  MIA_REQUIRE(workspace_bytes >= mia_whisper_stem_workspace_bytes(clips, frames, n_mels, n_state),
+              "workspace too small");
+  const int64_t t_out = (frames - 1) / 2 + 1;
+  MIA_REQUIRE(clips * frames < (1LL << 31) - 256, "batch too large for one call: %lld frames (split the batch)",
+              (long long)(clips * frames));
+  MIA_REQUIRE((reinterpret_cast<uintptr_t>(packed) & 15) == 0 && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0 &&
+                  (reinterpret_cast<uintptr_t>(out) & 15) == 0 && (reinterpret_cast<uintptr_t>(conv1_b) & 15) == 0 &&
+                  (reinterpret_cast<uintptr_t>(conv2_b) & 15) == 0 && (reinterpret_cast<uintptr_t>(pos) & 15) == 0,
+              "pointers must be 16-byte aligned");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int cp = stem_cpad(n_mels);
+  const _Float16* w1 = static_cast<const _Float16*>(packed);
+  const _Float16* w2 = reinterpret_cast<const _Float16*>(static_cast<const unsigned char*>(packed) +
+                                                         stem_align((size_t)n_state * 3 * cp * 2));
+  _Float16* x0 = static_cast<_Float16*>(workspace);
+  _Float16* h1 = reinterpret_cast<_Float16*>(static_cast<unsigned char*>(workspace) +
+                                             stem_align((size_t)clips * (frames + 2) * cp * 2));
+  const unsigned gy = 32768;  // clips per launch of the two small kernels (grid.y limit)
+  for (int64_t c0 = 0; c0 < clips; c0 += gy) {
+    const unsigned nc = (unsigned)(clips - c0 < gy ? clips - c0 : gy);
+    hipLaunchKernelGGL(stem_prep_kernel, dim3((unsigned)((frames + 2 + 63) / 64), nc), dim3(256),
+                       (size_t)64 * (cp + 8) * 2, s, mel + c0 * n_mels * frames, n_mels, (int)frames, cp,
+                       x0 + c0 * (frames + 2) * cp);
+    hipLaunchKernelGGL(stem_zero_rows_kernel, dim3(2, nc), dim3(256), 0, s, h1 + c0 * (frames + 2) * n_state,
+                       (long long)(frames + 2), n_state);
+  }
+  stem::Gemm g1{x0, frames + 2, cp, 1, (int)frames, (int)(clips * frames), w1, conv1_b, nullptr, n_state,
+                h1, frames + 2, 1};
+  {
+    const long long tiles = ((long long)g1.m_total + stem::BM - 1) / stem::BM * (n_state / stem::BN);
+    MIA_REQUIRE(tiles < (1LL << 31), "batch too large for one launch");
+    hipLaunchKernelGGL(stem_gemm_kernel<true>, dim3((unsigned)tiles), dim3(stem::WG), 0, s, g1);
+  }
+  stem::Gemm g2{h1, frames + 2, n_state, 2, (int)t_out, (int)(clips * t_out), w2, conv2_b, pos, n_state,
+                out, t_out, 0};
+  {
+    const long long tiles = ((long long)g2.m_total + stem::BM - 1) / stem::BM * (n_state / stem::BN);
+    if (out_f16) {
+      hipLaunchKernelGGL(stem_gemm_kernel<true>, dim3((unsigned)tiles), dim3(stem::WG), 0, s, g2);
+    } else {
+      hipLaunchKernelGGL(stem_gemm_kernel<false>, dim3((unsigned)tiles), dim3(stem::WG), 0, s, g2);
+    }
+  }
+  MIA_CHECK_HIP(hipGetLastError());
+  return MIA_OK;
+}
+
+}  // extern "C"
