@@ -11,8 +11,10 @@
 //
 //   stem_prep_kernel   log-mel (clips, n_mels, frames) float32, frames contiguous
 //                      -> (clips, frames + 2, C_pad) float16, channels contiguous, zero rows/pad
-//   stem_gemm_kernel   tile = 128 output channels x 128 output frames x 64 of K; 4 waves, each
-//                      64 x 64 as 2 x 2 accumulators of 32 x 32; both operand tiles arrive by
+//   stem_gemm_kernel   tile = 256 output channels x 256 output frames x 64 of K with 8 waves, each
+//                      128 x 64 as 4 x 2 accumulators of 32 x 32 (half the operand bytes per
+//                      multiply-add of a 128 x 128 tile, which serves small batches and channel
+//                      counts 256 does not divide); both operand tiles arrive by
 //                      LDS-DMA (global_load_lds_dwordx4) into a double buffer, XOR-swizzled on the
 //                      source address so that the ds_read_b128 fragment reads are conflict-free;
 //                      epilogue: + bias, GELU, (+ positional embedding), float16 rows staged
@@ -24,14 +26,10 @@
 
 namespace mia {
 namespace stem {
-constexpr int BM = 128, BN = 128, BK = 64, WG = 256;
-constexpr int TILE_BYTES = 128 * BK * 2;        // one operand tile: 128 rows x 128 bytes
-constexpr int BUF_BYTES = 2 * TILE_BYTES;       // weights | activations
-constexpr int STAGE_PITCH = BN * 2 + 16;        // float16 output rows in LDS: 16-byte aligned, 4 m mod 32 banks
+constexpr int BK = 64;  // halves of K per step: 128-byte operand rows in LDS
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef float f16v __attribute__((ext_vector_type(16)));
-static_assert(BM * STAGE_PITCH <= 2 * BUF_BYTES, "the output tile fits the operand buffers");
 
 struct Gemm {
   const _Float16* act;  // (clips, rows_in, cin): zero row, frames, zero row
@@ -80,10 +78,28 @@ __device__ __forceinline__ float gelu(float x) {
 }
 }  // namespace stem
 
-template <bool OUT_F16>
-__global__ __launch_bounds__(stem::WG, 2) void stem_gemm_kernel(stem::Gemm p) {
+// Tile shape: NWR x NWC waves, each RN x RM accumulators of 32 channels x 32 frames.
+template <int NWR_, int NWC_, int RN_, int RM_, int OCC_>
+struct StemTile {
+  static constexpr int NWR = NWR_, NWC = NWC_, RN = RN_, RM = RM_, OCC = OCC_;
+  static constexpr int NW = NWR * NWC, WG = 64 * NW;
+  static constexpr int BN = 32 * RN * NWR, BM = 32 * RM * NWC;       // channels x frames of a tile
+  static constexpr int W_BYTES = BN * 128, A_BYTES = BM * 128;       // operand tiles of one K-step
+  static constexpr int BUF_BYTES = W_BYTES + A_BYTES;
+  static constexpr int PW = BN / (8 * NW), PA = BM / (8 * NW);       // DMA pieces per wave and K-step
+  static constexpr int STAGE_PITCH = BN * 2 + 16;                    // float16 output rows in LDS
+  static constexpr int LDS_BYTES = 2 * BUF_BYTES > BM * STAGE_PITCH ? 2 * BUF_BYTES : BM * STAGE_PITCH;
+  static_assert(BN % (8 * NW) == 0 && BM % (8 * NW) == 0, "whole DMA pieces per wave");
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+};
+using StemTile128 = StemTile<2, 2, 2, 2, 2>;  // 128 x 128, 4 waves, two workgroups per CU
+using StemTile256 = StemTile<2, 4, 4, 2, 1>;  // 256 x 256, 8 waves, one workgroup per CU
+
+template <class TL, bool OUT_F16>
+__global__ __launch_bounds__(TL::WG, TL::OCC) void stem_gemm_kernel(stem::Gemm p) {
   using namespace stem;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUF_BYTES];
+  constexpr int BN = TL::BN, BM = TL::BM, WG = TL::WG;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
 
@@ -97,41 +113,48 @@ __global__ __launch_bounds__(stem::WG, 2) void stem_gemm_kernel(stem::Gemm p) {
   const int m0 = (int)(logical / (unsigned)nt) * BM;
   const int K = 3 * p.cin;
 
-  // ---- sources of this thread's DMA pieces: piece s = (4 wv + i) * 64 + lane of a tile is
+  // ---- sources of this thread's DMA pieces: piece s = (P wv + i) * 64 + lane of a tile is
   // LDS slot s = row * 8 + c'; it holds the 16 bytes of chunk c = c' ^ ((row >> 1) & 7) ----
-  const _Float16* wsrc[4];
-  const _Float16* asrc[4];
+  const _Float16* wsrc[TL::PW];
+  const _Float16* asrc[TL::PA];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int s = (4 * wv + i) * 64 + lane;
+  for (int i = 0; i < TL::PW; ++i) {
+    const int s = (TL::PW * wv + i) * 64 + lane;
     const int row = s >> 3, c = (s & 7) ^ ((row >> 1) & 7);
     wsrc[i] = p.w + ((size_t)(n0 + row) * K + 8 * c);
+  }
+#pragma unroll
+  for (int i = 0; i < TL::PA; ++i) {
+    const int s = (TL::PA * wv + i) * 64 + lane;
+    const int row = s >> 3, c = (s & 7) ^ ((row >> 1) & 7);
     int m = m0 + row;
     m = m < p.m_total ? m : p.m_total - 1;  // rows past the end repeat the last one; never stored
     const int clip = m / p.t_out, t = m - clip * p.t_out;
     asrc[i] = p.act + (((size_t)clip * p.rows_in + (size_t)p.stride * t) * p.cin + 8 * c);
   }
   const unsigned lds0 = (unsigned)(unsigned long long)(smem);
-  const unsigned dst0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + 4096u * wv));
+  const unsigned wdst = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + 1024u * TL::PW * wv));
+  const unsigned adst =
+      (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + TL::W_BYTES + 1024u * TL::PA * wv));
   auto issue = [&](int ks, int buf) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) dma16(wsrc[i] + ks * BK, dst0 + buf * BUF_BYTES + 1024u * i);
+    for (int i = 0; i < TL::PW; ++i) dma16(wsrc[i] + ks * BK, wdst + buf * TL::BUF_BYTES + 1024u * i);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) dma16(asrc[i] + ks * BK, dst0 + buf * BUF_BYTES + TILE_BYTES + 1024u * i);
+    for (int i = 0; i < TL::PA; ++i) dma16(asrc[i] + ks * BK, adst + buf * TL::BUF_BYTES + 1024u * i);
   };
 
   // ---- fragment reads: lane l holds elements k = 8 (l >> 5) + j of row l & 31 -------------
-  const int wr = wv >> 1, wc = wv & 1;  // the wave's 64 channels x 64 frames of the tile
+  const int wr = wv / TL::NWC, wc = wv % TL::NWC;  // the wave's block of channels / of frames
   const int r31 = lane & 31;
   const int e = (lane >> 5) ^ ((r31 >> 1) & 7);
-  const unsigned char* wbase = smem + (wr * 64 + r31) * 128;
-  const unsigned char* abase = smem + TILE_BYTES + (wc * 64 + r31) * 128;
+  const unsigned char* wbase = smem + (wr * 32 * TL::RN + r31) * 128;
+  const unsigned char* abase = smem + TL::W_BYTES + (wc * 32 * TL::RM + r31) * 128;
 
-  f16v acc[2][2];
+  f16v acc[TL::RN][TL::RM];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < TL::RN; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < TL::RM; ++b)
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
 
@@ -144,30 +167,31 @@ __global__ __launch_bounds__(stem::WG, 2) void stem_gemm_kernel(stem::Gemm p) {
     if (ks + 1 < nk) issue(ks + 1, buf ^ 1);
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-      const int off = buf * BUF_BYTES + (((2 * kk) ^ e) << 4);
-      h8 a[2], b[2];
+      const int off = buf * TL::BUF_BYTES + (((2 * kk) ^ e) << 4);
+      h8 a[TL::RN], b[TL::RM];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        a[i] = *reinterpret_cast<const h8*>(wbase + off + i * 32 * 128);
-        b[i] = *reinterpret_cast<const h8*>(abase + off + i * 32 * 128);
-      }
+      for (int i = 0; i < TL::RN; ++i) a[i] = *reinterpret_cast<const h8*>(wbase + off + i * 32 * 128);
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni)
+      for (int i = 0; i < TL::RM; ++i) b[i] = *reinterpret_cast<const h8*>(abase + off + i * 32 * 128);
+      __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+      for (int ni = 0; ni < TL::RN; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < TL::RM; ++mi)
           acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ni], b[mi], acc[ni][mi], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
     }
     // the next tile has landed, and every wave is done reading this one
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
 
-  // ---- epilogue: acc[ni][mi][reg] = channel n0 + 64 wr + 32 ni + (reg & 3) + 8 (reg >> 2)
-  // + 4 (lane >> 5) of frame m0 + 64 wc + 32 mi + (lane & 31) ----------------------------------
+  // ---- epilogue: acc[ni][mi][reg] = channel n0 + 32 (RN wr + ni) + (reg & 3) + 8 (reg >> 2)
+  // + 4 (lane >> 5) of frame m0 + 32 (RM wc + mi) + (lane & 31) --------------------------------
   const int h = lane >> 5;
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi) {
-    const int ml = wc * 64 + mi * 32 + r31;
+  for (int mi = 0; mi < TL::RM; ++mi) {
+    const int ml = 32 * (TL::RM * wc + mi) + r31;
     const int m = m0 + ml;
     const bool live = m < p.m_total;
     const int mc = live ? m : p.m_total - 1;
@@ -176,10 +200,10 @@ __global__ __launch_bounds__(stem::WG, 2) void stem_gemm_kernel(stem::Gemm p) {
     float* __restrict__ orow =
         reinterpret_cast<float*>(p.out) + ((size_t)clip * p.out_rows + p.out_row0 + t) * p.n;
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
+    for (int ni = 0; ni < TL::RN; ++ni) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int nl = wr * 64 + ni * 32 + 8 * g + 4 * h;
+        const int nl = 32 * (TL::RN * wr + ni) + 8 * g + 4 * h;
         const float4 bv = *reinterpret_cast<const float4*>(p.bias + n0 + nl);
         float4 v = {gelu(acc[ni][mi][4 * g] + bv.x), gelu(acc[ni][mi][4 * g + 1] + bv.y),
                     gelu(acc[ni][mi][4 * g + 2] + bv.z), gelu(acc[ni][mi][4 * g + 3] + bv.w)};
@@ -189,7 +213,7 @@ __global__ __launch_bounds__(stem::WG, 2) void stem_gemm_kernel(stem::Gemm p) {
         }
         if (OUT_F16) {
           const h4 hv = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
-          *reinterpret_cast<h4*>(smem + ml * STAGE_PITCH + nl * 2) = hv;
+          *reinterpret_cast<h4*>(smem + ml * TL::STAGE_PITCH + nl * 2) = hv;
         } else if (live) {
           *reinterpret_cast<float4*>(orow + n0 + nl) = v;
         }
@@ -198,21 +222,47 @@ __global__ __launch_bounds__(stem::WG, 2) void stem_gemm_kernel(stem::Gemm p) {
   }
   if (OUT_F16) {
     __syncthreads();
-    // 128 rows x 16 pieces of 16 bytes: 16 consecutive lanes store one row's 256 bytes
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int idx = j * WG + tid;
-      const int row = idx >> 4, cp = idx & 15;
+    // BM rows x BN / 8 pieces of 16 bytes: BN / 8 consecutive lanes store one row's run
+    constexpr int PIECES = BN / 8;
+#pragma unroll 4
+    for (int idx = tid; idx < BM * PIECES; idx += WG) {
+      const int row = idx / PIECES, cp = idx % PIECES;
       const int m = m0 + row;
       if (m < p.m_total) {
         const int clip = m / p.t_out, t = m - clip * p.t_out;
-        const uint4 v = *reinterpret_cast<const uint4*>(smem + row * STAGE_PITCH + cp * 16);
+        const uint4 v = *reinterpret_cast<const uint4*>(smem + row * TL::STAGE_PITCH + cp * 16);
         _Float16* __restrict__ orow =
             reinterpret_cast<_Float16*>(p.out) + ((size_t)clip * p.out_rows + p.out_row0 + t) * p.n;
         *reinterpret_cast<uint4*>(orow + n0 + 8 * cp) = v;
       }
     }
   }
+}
+
+template <class TL, bool OUT_F16>
+static int launch_stem_gemm(const stem::Gemm& g, hipStream_t s) {
+  const long long tiles = ((long long)g.m_total + TL::BM - 1) / TL::BM * (g.n / TL::BN);
+  if (tiles >= (1LL << 31)) {
+    set_error("batch too large for one launch");
+    return MIA_ERR_UNSUPPORTED;
+  }
+  auto kern = stem_gemm_kernel<TL, OUT_F16>;
+  static bool attr_set = false;  // (per instantiation; the attribute is a property of the function)
+  if (!attr_set) {
+    MIA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, TL::LDS_BYTES));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(TL::WG), TL::LDS_BYTES, s, g);
+  return MIA_OK;
+}
+// The 256 x 256 tile moves half the operand bytes per multiply-add; it needs enough tiles to
+// fill the chip and a channel count it divides.
+template <bool OUT_F16>
+static int dispatch_stem_gemm(const stem::Gemm& g, int cus, hipStream_t s) {
+  const long long tiles256 = ((long long)g.m_total + 255) / 256 * (g.n / 256);
+  if (g.n % 256 == 0 && tiles256 >= 2LL * cus) return launch_stem_gemm<StemTile256, OUT_F16>(g, s);
+  return launch_stem_gemm<StemTile128, OUT_F16>(g, s);
 }
 
 // log-mel (clips, C, T) float32 -> (clips, T + 2, CP) float16, channels contiguous; rows 0 and
@@ -339,23 +389,17 @@ int mia_whisper_stem(const float* mel, int64_t clips, int64_t frames, int n_mels
     hipLaunchKernelGGL(stem_zero_rows_kernel, dim3(2, nc), dim3(256), 0, s, h1 + c0 * (frames + 2) * n_state,
                        (long long)(frames + 2), n_state);
   }
+  int dev = 0, cus = 256;
+  MIA_CHECK_HIP(hipGetDevice(&dev));
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   stem::Gemm g1{x0, frames + 2, cp, 1, (int)frames, (int)(clips * frames), w1, conv1_b, nullptr, n_state,
                 h1, frames + 2, 1};
-  {
-    const long long tiles = ((long long)g1.m_total + stem::BM - 1) / stem::BM * (n_state / stem::BN);
-    MIA_REQUIRE(tiles < (1LL << 31), "batch too large for one launch");
-    hipLaunchKernelGGL(stem_gemm_kernel<true>, dim3((unsigned)tiles), dim3(stem::WG), 0, s, g1);
-  }
+  int rc = dispatch_stem_gemm<true>(g1, cus, s);
+  if (rc != MIA_OK) return rc;
   stem::Gemm g2{h1, frames + 2, n_state, 2, (int)t_out, (int)(clips * t_out), w2, conv2_b, pos, n_state,
                 out, t_out, 0};
-  {
-    const long long tiles = ((long long)g2.m_total + stem::BM - 1) / stem::BM * (n_state / stem::BN);
-    if (out_f16) {
-      hipLaunchKernelGGL(stem_gemm_kernel<true>, dim3((unsigned)tiles), dim3(stem::WG), 0, s, g2);
-    } else {
-      hipLaunchKernelGGL(stem_gemm_kernel<false>, dim3((unsigned)tiles), dim3(stem::WG), 0, s, g2);
-    }
-  }
+  rc = out_f16 ? dispatch_stem_gemm<true>(g2, cus, s) : dispatch_stem_gemm<false>(g2, cus, s);
+  if (rc != MIA_OK) return rc;
   MIA_CHECK_HIP(hipGetLastError());
   return MIA_OK;
 }

@@ -88,3 +88,21 @@ def test_stem_argument_checks():
     lib = _lib.lib()
     assert lib.mia_whisper_stem_workspace_bytes(0, 10, 80, 128) == 0
     assert stem(torch.zeros((0, 80, 6))).shape == (0, 3, 128)
+
+
+def test_large_batch_tile_equals_small_batch_tile():
+    """Batches large enough to fill the chip take the 256 x 256 tile, small ones the 128 x 128
+    tile; every output element sums its products in the same order in both, so the results are
+    equal bit for bit.  One clip is also checked against the oracle."""
+    w1, b1, w2, b2 = _weights(128, 1280, 11)
+    pos = sinusoids(1500, 1280)
+    stem = WhisperEncoderStem(w1, b1, w2, b2, pos)
+    g = torch.Generator(device="cuda").manual_seed(12)
+    mel = 0.5 * torch.randn((40, 128, 3000), device="cuda", generator=g)
+    for dt in (torch.float16, torch.float32):
+        full = stem(mel, out_dtype=dt)
+        for i in (0, 17, 39):
+            assert torch.equal(full[i:i + 1], stem(mel[i:i + 1], out_dtype=dt)), (dt, i)
+    want = _oracle_f16_model(mel[17:18].cpu().numpy(), w1, b1, w2, b2, pos.numpy())
+    got = full[17:18].cpu().numpy()
+    assert np.abs(got - want).max() <= 2e-3 * np.abs(want).max()
