@@ -44,10 +44,30 @@ def stream_ptr(device: torch.device) -> int:
     return torch.cuda.current_stream(device).cuda_stream
 
 
+# Digests of the table arrays.  The mirror's table builders are lru-cached as immutable
+# `bytes` and handed out as read-only views of them, so the digest is remembered per bytes
+# object (a Whisper call would otherwise hash ~100 KB of filterbank every time); any other
+# array is hashed on every call.
+_digests: "OrderedDict[int, tuple[bytes, str]]" = OrderedDict()
+
+
 def _digest(a: np.ndarray | None) -> str:
     if a is None:
         return "-"
-    return hashlib.sha1(np.ascontiguousarray(a).tobytes()).hexdigest()
+    base = a
+    while isinstance(base, np.ndarray) and base.base is not None:
+        base = base.base
+    whole = isinstance(base, bytes) and a.nbytes == len(base) and a.flags.c_contiguous
+    if whole:
+        hit = _digests.get(id(base))
+        if hit is not None and hit[0] is base:
+            return hit[1]
+    d = hashlib.sha1(np.ascontiguousarray(a).tobytes()).hexdigest()
+    if whole:
+        _digests[id(base)] = (base, d)  # holds the bytes, so the id cannot be reused
+        while len(_digests) > 256:
+            _digests.popitem(last=False)
+    return d
 
 
 def _fptr(a: np.ndarray | None):
@@ -102,6 +122,14 @@ class Plan:
             finally:
                 self.handle = None
 
+    def __del__(self):
+        # The plan is destroyed when its last holder lets go of it: the cache only drops its
+        # reference on eviction, so a caller that still works with an evicted plan keeps it alive.
+        try:
+            self.close()
+        except Exception:
+            pass
+
 
 _plans: "OrderedDict[tuple, Plan]" = OrderedDict()
 _plans_lock = threading.Lock()
@@ -125,13 +153,10 @@ def get_plan(device: torch.device, n_fft: int, hop: int, center: bool, pad_mode:
                     mel_basis, power, dct_basis, lifter)
         _plans[key] = plan
         while len(_plans) > _PLAN_CACHE_MAX:
-            _, old = _plans.popitem(last=False)
-            old.close()
+            _plans.popitem(last=False)  # freed by Plan.__del__ once no caller holds it
         return plan
 
 
 def clear_plans() -> None:
     with _plans_lock:
-        while _plans:
-            _, old = _plans.popitem()
-            old.close()
+        _plans.clear()

@@ -22,7 +22,15 @@ def _to_db(S, ref, coefficient: float, amin: float, top_db, per_clip: bool) -> t
     S = S.to(torch.float32).contiguous()
     if top_db is not None and top_db <= 0:
         raise ValueError(f"top_db must be positive, got {top_db}")
-    ref_value = float(ref(S)) if callable(ref) else float(ref)
+    if callable(ref):
+        # the reference hands its array to the callable (convert.py:42-44); NumPy reducers such
+        # as np.max - the usual idiom - do not take a device tensor, so they get a host copy
+        try:
+            ref_value = float(ref(S))
+        except (TypeError, RuntimeError, ValueError):
+            ref_value = float(ref(S.detach().cpu().numpy()))
+    else:
+        ref_value = float(ref)
     if per_clip and S.dim() >= 2:
         B, n = S.shape[0], S[0].numel()
     else:

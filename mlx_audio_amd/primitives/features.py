@@ -210,6 +210,9 @@ def spectral_flatness(y=None, S=None, n_fft: int = 2048, hop_length: int = 512, 
     return _stat(S, "flatness", amin=amin, power=power if from_y else 1.0)
 
 
+_CONTRAST_MAX_Q = 64  # values per quantile the kernel's sorted register arrays hold
+
+
 def _contrast_bands(freq: np.ndarray, fmin: float, n_bands: int, quantile: float) -> np.ndarray:
     """(n_bands + 1, 3) int32 rows {first bin, one past the last bin, values per quantile} of
     the octave bands [0, fmin], [fmin, 2 fmin], ... (reference features.py:566-599): a band takes
@@ -266,13 +269,29 @@ def spectral_contrast(y=None, sr: int = 22050, S=None, n_fft: int = 2048, hop_le
         raise ValueError(f"freq has {freq_np.size} entries but the spectrogram has {bins} bins")
     bands = _contrast_bands(freq_np, float(fmin), int(n_bands), float(quantile))
     live = bands[:, 1] - bands[:, 0] > bands[:, 2]   # bands that actually select quantiles
-    max_q = int(bands[live, 2].max()) if live.any() else 1
-    bands_dev = torch.from_numpy(bands).to(Sb.device)
+    # The kernel keeps at most 64 values per quantile in registers.  Bands that need more (wide
+    # top bands with a large quantile, or very long transforms) are rare: they are handed to the
+    # kernel as empty bands and filled in below from a device sort of just their bins.
+    wide = live & (bands[:, 2] > _CONTRAST_MAX_Q)
+    kbands = bands.copy()
+    kbands[wide] = (0, 0, 1)
+    max_q = int(kbands[live & ~wide, 2].max()) if (live & ~wide).any() else 1
+    bands_dev = torch.from_numpy(kbands).to(Sb.device)
     out = torch.empty((rows, n_bands + 1, frames), dtype=torch.float32, device=Sb.device)
     with torch.cuda.device(Sb.device):
         _lib.check(_lib.lib().mia_spectral_contrast(
             Sb.data_ptr(), rows, bins, frames, bands_dev.data_ptr(), n_bands + 1, max_q,
             int(bool(linear)), out.data_ptr(), stream_ptr(Sb.device)))
+    for k in np.flatnonzero(wide):
+        lo, hi, nq = (int(v) for v in bands[k])
+        band = torch.sort(Sb[:, lo:hi, :], dim=1).values
+        valley = band[:, :nq, :].mean(dim=1)
+        peak = band[:, hi - lo - nq:, :].mean(dim=1)
+        if linear:
+            out[:, k, :] = peak - valley
+        else:
+            out[:, k, :] = (10.0 * torch.log10(torch.clamp(peak, min=1e-10))
+                            - 10.0 * torch.log10(torch.clamp(valley, min=1e-10)))
     return out if batched else out[0]
 
 

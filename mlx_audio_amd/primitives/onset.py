@@ -77,7 +77,11 @@ def onset_detect(y=None, sr: int = 22050, onset_envelope=None, hop_length: int =
                  post_max: int = 1, pre_avg: int = 1, post_avg: int = 1, delta: float = 0.07,
                  wait: int = 1, **kwargs) -> torch.Tensor:
     """Peak picking on the onset envelope (reference onset.py:181-322).  As in the reference
-    the scan runs on the host and, for a batched envelope, looks at the first row only."""
+    the scan runs on the host and, for a batched envelope, looks at the first row only; the
+    result has the types `mx.array` gives the reference's NumPy result: int64 frame / sample
+    indices as they are, times narrowed from float64 to float32."""
+    if hop_length <= 0:
+        raise ValueError(f"hop_length must be positive, got {hop_length}")
     if onset_envelope is None:
         if y is None:
             raise ValueError("Either y (audio) or onset_envelope must be provided")
@@ -114,7 +118,8 @@ def onset_detect(y=None, sr: int = 22050, onset_envelope=None, hop_length: int =
         result = (onsets * hop_length) / sr
     else:
         raise ValueError(f"Unknown units: '{units}'. Use 'frames', 'samples', or 'time'")
-    return torch.from_numpy(np.asarray(result))
+    result = np.asarray(result)
+    return torch.from_numpy(result.astype(np.float32) if result.dtype.kind == "f" else result)
 
 
 def onset_strength_multi(y, sr: int = 22050, n_fft: int = 2048, hop_length: int = 512,

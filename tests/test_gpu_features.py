@@ -132,9 +132,16 @@ def test_spectral_contrast_from_a_waveform_and_limits(gpu):
     want = orc.spectral_contrast(y, sr=22050)
     assert got.shape == want.shape
     np.testing.assert_allclose(got, want, rtol=1e-4, atol=2e-3)
-    S = _spec(rng, (1, 4097, 5))   # 0.2 of the 2800-bin top band is far more than 64 values
-    with pytest.raises(NotImplementedError, match="exceed the supported 64"):
-        spectral_contrast(S=_dev(S, gpu), sr=44100, n_fft=8192, quantile=0.2)
+    S = _spec(rng, (1, 4097, 5))   # 0.2 of the 2800-bin top band is far more than 64 values:
+    got = spectral_contrast(S=_dev(S, gpu), sr=44100, n_fft=8192, quantile=0.2).cpu().numpy()
+    want = orc.spectral_contrast(S=S, sr=44100, n_fft=8192, quantile=0.2)   # ... bands by sorting
+    np.testing.assert_allclose(got, want, rtol=2e-5, atol=3e-5)
+    # the C entry point itself still refuses what its register arrays cannot hold
+    bands = torch.tensor([[0, 4097, 100]], dtype=torch.int32, device=gpu)
+    out = torch.empty((1, 1, 5), device=gpu)
+    rc = _lib.lib().mia_spectral_contrast(_dev(S, gpu).data_ptr(), 1, 4097, 5, bands.data_ptr(), 1, 100, 0,
+                                          out.data_ptr(), None)
+    assert rc == _lib.MIA_ERR_UNSUPPORTED
 
 
 @pytest.mark.parametrize("n_fft,hop", [(2048, 512), (1024, 256), (400, 160), (512, 128), (4096, 1024), (256, 64), (800, 200)])
@@ -227,3 +234,15 @@ def test_full_size_batch_properties(gpu):
     assert torch.equal(spectral_rolloff(S=S4, sr=16000), r)
     assert torch.allclose(spectral_flatness(S=S4), fl, rtol=1e-5)
     assert torch.allclose(spectral_bandwidth(S=S4, sr=16000), b, rtol=1e-6)
+
+
+def test_contrast_wide_quantile_bands():
+    """More than 64 values per quantile in a band (44.1 kHz, quantile 0.1: the top band holds
+    ~730 bins): those bands come from a device sort instead of the register arrays; against
+    the oracle like every other case."""
+    g = torch.Generator(device="cuda").manual_seed(5)
+    S = torch.rand((3, 1025, 40), device="cuda", generator=g) + 0.01
+    got = spectral_contrast(S=S, sr=44100, quantile=0.1).cpu().numpy()
+    want = orc.spectral_contrast(S=S.cpu().numpy(), sr=44100, n_fft=2048, quantile=0.1)
+    assert got.shape == want.shape
+    assert np.allclose(got, want, rtol=2e-5, atol=2e-5)

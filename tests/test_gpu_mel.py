@@ -274,3 +274,16 @@ def test_logmel_whisper_unswept_filterbank_uses_generic_kernel(gpu):
         got = melspectrogram(torch.from_numpy(x).to(gpu), sr=16000, n_fft=400, hop_length=160, **kw)
         ref = o.melspectrogram(x, sr=16000, n_fft=400, hop_length=160, **kw)
         np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=1e-4, atol=1e-5 * ref.max())
+
+
+def test_power_to_db_callable_ref():
+    """`ref=np.max` (the usual idiom) works on a device tensor, as does a torch reducer."""
+    from mlx_audio_amd.primitives import power_to_db
+
+    g = torch.Generator(device="cuda").manual_seed(2)
+    S = torch.rand((4, 64, 50), device="cuda", generator=g) + 1e-3
+    a = power_to_db(S, ref=np.max).cpu().numpy()
+    b = power_to_db(S, ref=torch.max).cpu().numpy()
+    c = power_to_db(S, ref=float(S.max())).cpu().numpy()
+    assert np.array_equal(a, c) and np.array_equal(b, c)
+    assert abs(a.max()) < 1e-6
