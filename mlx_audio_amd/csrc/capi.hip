@@ -975,6 +975,14 @@ int mia_mfcc(const mia_plan* plan, const float* y, int64_t B, int64_t T, float t
   if ((rc = launch_init_keys(keys, min_keys, B + 1, s)) != MIA_OK) return rc;
   p.clip_max_key = keys;
   p.clip_min_key = min_keys;
+  // The dB values are an intermediate of this call, so their layout is free: when the generic
+  // mel kernel and the matrix-core DCT serve the plan, they go frame-major - a tile of a few
+  // frames then leaves as one contiguous run of whole lines instead of n_mels short row
+  // fragments (which reach memory as read-modify-write pairs), and the DCT reads whole runs.
+  const bool fm = !plan->generic && plan->d_sweep_meta == nullptr &&
+                  forward_frame_major_ok(plan->n_fft, plan->n_mels) &&
+                  dct2_frame_major_ok(plan->n_mels, plan->n_mfcc);
+  p.frame_major = fm ? 1 : 0;
   {
     const size_t keys_bytes = 2 * align256(sizeof(int) * (size_t)(B + 1));
     rc = forward_mel_dispatch(plan, p, s, reinterpret_cast<char*>(workspace) + keys_bytes,
@@ -985,6 +993,11 @@ int mia_mfcc(const mia_plan* plan, const float* y, int64_t B, int64_t T, float t
     // global maximum: fold keys[0..B) into keys[B]
     rc = launch_reduce_keys(keys, B, s);
     if (rc != MIA_OK) return rc;
+  }
+  if (fm) {
+    return launch_dct2_frame_major(sdb, B, plan->n_mels, F, plan->d_dct, plan->n_mfcc, out,
+                                   clamp ? (per_clip ? keys : keys + B) : nullptr,
+                                   (long long)(per_clip ? 1 : 0), top_db, s);
   }
   return launch_dct2(sdb, B, plan->n_mels, F, plan->d_dct, plan->n_mfcc, out,
                      clamp ? (per_clip ? keys : keys + B) : nullptr,

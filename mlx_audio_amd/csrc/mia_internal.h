@@ -138,6 +138,7 @@ struct FwdParams {
   float db_floor_shift;  // coef*log10(1/max(ref,amin)): additive form of the division by ref
   int* clip_max_key;   // B (+1) keys of the per-clip maximum, or nullptr
   int* clip_min_key;   // B keys of the per-clip minimum of the stored values
+  int frame_major;     // generic mel kernel: write (B, F, n_mels) rows instead of (B, n_mels, F)
   int dbg;
   // spectral-statistics epilogue (epi == kEpiStats): centroid, bandwidth, roll-off, flatness
   const float* freq;   // bin frequencies
@@ -197,5 +198,10 @@ int launch_forward_generic(const mia_plan* plan, const FwdParams& p, int mode, v
 int launch_inverse_generic(const mia_plan* plan, const InvParams& p, void* workspace,
                            size_t workspace_bytes, hipStream_t s);
 int forward_tile_frames(int n_fft, int mode);
+bool forward_frame_major_ok(int n_fft, int n_mels);
+bool dct2_frame_major_ok(int n_in, int n_out);
+int launch_dct2_frame_major(const float* x, long long outer, int n_in, long long inner, const float* basis,
+                            int n_out, float* out, const int* keys, long long key_stride, float top,
+                            hipStream_t s);
 
 }  // namespace mia

@@ -413,6 +413,131 @@ __global__ __launch_bounds__(256) void dct2_mfma_kernel(const float* __restrict_
   }
 }
 
+// The same kernel for input stored position-major, x[o, i, n] (the layout the generic mel kernel
+// writes for the MFCC path: a tile of 64 positions is one contiguous run of 64 * n_in floats).
+// Needs n_in % 4 == 0.  The slab is [position][n_in + 4]: whole float4 stores when staging, and
+// the B operand reads (16 positions x 4 taps per wave instruction) are 2-way at most.
+__global__ __launch_bounds__(256) void dct2_mfma_fm_kernel(const float* __restrict__ x, int n_in,
+                                                            long long inner,
+                                                            const float* __restrict__ basis, int n_out,
+                                                            float* __restrict__ out,
+                                                            const int* __restrict__ keys,
+                                                            long long key_stride, float top,
+                                                            long long tiles_per_row, long long total,
+                                                            int tiles_per_wg) {
+  constexpr int PITCH = 4 * kDctKS + 4;
+  __shared__ __attribute__((aligned(16))) float slab[64 * PITCH];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int row = lane & 15, kq = lane >> 4;
+  float a[kDctMB][kDctKS];
+#pragma unroll
+  for (int mb = 0; mb < kDctMB; ++mb) {
+#pragma unroll
+    for (int ks = 0; ks < kDctKS; ++ks) {
+      const int m = 16 * mb + row, k = 4 * ks + kq;
+      a[mb][ks] = (m < n_out && k < n_in) ? basis[(long long)m * n_in + k] : 0.0f;
+    }
+  }
+  const long long first = (long long)blockIdx.x * tiles_per_wg;
+  const long long last = first + tiles_per_wg < total ? first + tiles_per_wg : total;
+  const int q4 = n_in / 4;              // float4 pieces per position
+  float4 nx[8];                         // 64 positions x <= 32 pieces = 2048 pieces / 256 threads
+  int nkey = 0;
+  auto fetch = [&](long long idx_n) {
+    const long long o = idx_n / tiles_per_row;
+    if (keys && idx_n < last) nkey = keys[o * key_stride];
+    const long long i0 = (idx_n - o * tiles_per_row) * 64;
+    const long long left = idx_n < last ? inner - i0 : 0;   // positions of the tile that exist
+    const float4* __restrict__ src = reinterpret_cast<const float4*>(x + (o * inner + i0) * n_in);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int idx = j * 256 + tid;
+      nx[j] = (idx < 64 * q4 && idx / q4 < left) ? src[idx] : float4{0.0f, 0.0f, 0.0f, 0.0f};
+    }
+  };
+  // zero the slab once: taps n_in .. 4 kDctKS - 1 stay zero (their A operands are zero too, but
+  // 0 * NaN of stale LDS contents would not be)
+  for (int i = tid; i < 64 * PITCH; i += 256) slab[i] = 0.0f;
+  fetch(first);
+  __syncthreads();
+  for (long long idx = first; idx < last; ++idx) {
+    const long long o = idx / tiles_per_row;
+    const long long i0 = (idx - o * tiles_per_row) * 64;
+    const float thr = keys ? floor_from_key(nkey, MIA_EPI_DB, top) : -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int idx4 = j * 256 + tid;
+      if (idx4 < 64 * q4) {
+        const int pos = idx4 / q4, n4 = idx4 - pos * q4;
+        const float4 v = {floor_nan(nx[j].x, thr), floor_nan(nx[j].y, thr), floor_nan(nx[j].z, thr),
+                          floor_nan(nx[j].w, thr)};
+        *reinterpret_cast<float4*>(slab + pos * PITCH + 4 * n4) = v;
+      }
+    }
+    __syncthreads();
+    fetch(idx + 1);
+    float bv[kDctKS];
+#pragma unroll
+    for (int ks = 0; ks < kDctKS; ++ks) bv[ks] = slab[(16 * wave + row) * PITCH + 4 * ks + kq];
+    dct_floatx4 acc[kDctMB];
+#pragma unroll
+    for (int mb = 0; mb < kDctMB; ++mb) acc[mb] = dct_floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int ks = 0; ks < kDctKS; ++ks) {
+#pragma unroll
+      for (int mb = 0; mb < kDctMB; ++mb) {
+        acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb][ks], bv[ks], acc[mb], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the prefetch, before this tile's stores
+    const long long pos = i0 + 16 * wave + row;
+    if (pos < inner) {
+#pragma unroll
+      for (int mb = 0; mb < kDctMB; ++mb) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = 16 * mb + 4 * kq + r;
+          if (m < n_out) out[(o * n_out + m) * inner + pos] = acc[mb][r];
+        }
+      }
+    }
+    __syncthreads();  // the next tile overwrites the slab
+  }
+}
+
+bool dct2_frame_major_ok(int n_in, int n_out) {
+  return n_in <= 4 * kDctKS && n_out <= 16 * kDctMB && n_in >= 32 && n_in % 4 == 0;
+}
+
+int launch_dct2_frame_major(const float* x, long long outer, int n_in, long long inner, const float* basis,
+                            int n_out, float* out, const int* keys, long long key_stride, float top,
+                            hipStream_t s) {
+  if (outer <= 0 || inner <= 0 || n_out <= 0) return MIA_OK;
+  if (!dct2_frame_major_ok(n_in, n_out)) {
+    set_error("dct: position-major input needs 32 <= n_in <= 128, n_in %% 4 == 0, n_out <= 48");
+    return MIA_ERR_UNSUPPORTED;
+  }
+  const long long tiles_per_row = (inner + 63) / 64;
+  const long long total = outer * tiles_per_row;
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  }
+  long long grid = 2LL * cus;
+  if (grid > total) grid = total;
+  const long long per_wg = (total + grid - 1) / grid;
+  if (per_wg > 0x7fffffffLL) {
+    set_error("dct: batch too large for one launch");
+    return MIA_ERR_UNSUPPORTED;
+  }
+  grid = (total + per_wg - 1) / per_wg;
+  hipLaunchKernelGGL(dct2_mfma_fm_kernel, dim3((unsigned)grid), dim3(256), 0, s, x, n_in, inner, basis,
+                     n_out, out, keys, key_stride, top, tiles_per_row, total, (int)per_wg);
+  MIA_CHECK_HIP(hipGetLastError());
+  return MIA_OK;
+}
+
 int launch_dct2(const float* x, long long outer, int n_in, long long inner, const float* basis,
                 int n_out, float* out, const int* keys, long long key_stride, float top,
                 hipStream_t s) {

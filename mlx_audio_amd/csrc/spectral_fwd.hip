@@ -232,8 +232,11 @@ __global__ __launch_bounds__(WG, C::OCC) void fwd_kernel(FwdParams p) {
   // Band tables of the mel stage: in LDS behind the power tile when the launcher found
   // room (one copy per persistent workgroup), else read from global memory.
   float* const lds_wts = P + FT * PS;
-  int* const lds_rows = reinterpret_cast<int*>(lds_wts + (MODE == 1 ? p.nnz : 0));
-  if constexpr (MODE == 1) {
+  // MODE 3 is MODE 1 (mel) with the tile written as (B, F, n_mels) rows: its own instantiation,
+  // so that the choice costs the mel kernels no registers.
+  constexpr bool MEL = MODE == 1 || MODE == 3;
+  int* const lds_rows = reinterpret_cast<int*>(lds_wts + (MEL ? p.nnz : 0));
+  if constexpr (MEL) {
     if (p.lds_tables) {
       for (int i = tid; i < p.nnz; i += WG) lds_wts[i] = p.wts[i];
       for (int i = tid; i < p.n_mels; i += WG) {
@@ -564,13 +567,16 @@ __global__ __launch_bounds__(WG, C::OCC) void fwd_kernel(FwdParams p) {
     }
     __syncthreads();  // the next tile overwrites the magnitude rows
   }
-  if constexpr (MODE == 1) {
+  if constexpr (MEL) {
     __syncthreads();
     const long long frem = p.F - f0;
     const int fcount = frem < FT ? (int)frem : FT;
     int kmax = kKeyMinusInf;  // integer keys: a NaN value wins the maximum, as in the reference
     float vmin = INFINITY;
     // one instantiation per table location, so that each knows its address space
+    // frame_major: the tile's values go to (B, F, n_mels) rows through the (now idle) FFT
+    // buffers, so that the tile leaves as one contiguous run of whole lines
+    float* const stage = reinterpret_cast<float*>(bufs);
     auto project = [&](const int* row_lo, const int* row_len, const int* row_off, const float* wts) {
       for (int idx2 = tid; idx2 < p.n_mels * FT; idx2 += WG) {
         const int m = idx2 / FT;
@@ -594,13 +600,25 @@ __global__ __launch_bounds__(WG, C::OCC) void fwd_kernel(FwdParams p) {
           kmax = max(kmax, float_to_key_nan(outv));
           vmin = fminf(vmin, outv);
         }
-        p.mout[(b * p.n_mels + m) * p.F + f0 + fl] = outv;
+        if (MODE == 3) {
+          stage[fl * p.n_mels + m] = outv;
+        } else {
+          p.mout[(b * p.n_mels + m) * p.F + f0 + fl] = outv;
+        }
       }
     };
     if (p.lds_tables) {
       project(lds_rows, lds_rows + p.n_mels, lds_rows + 2 * p.n_mels, lds_wts);
     } else {
       project(p.row_lo, p.row_len, p.row_off, p.wts);
+    }
+    if (MODE == 3) {
+      __syncthreads();
+      float* __restrict__ dst = p.mout + (b * p.F + f0) * p.n_mels;  // 16-byte aligned: n_mels % 4 == 0
+      const int n4 = fcount * p.n_mels / 4;
+      for (int i = tid; i < n4; i += WG) {
+        reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(stage)[i];
+      }
     }
     if (p.epi != MIA_EPI_NONE && p.clip_max_key != nullptr) {
 #pragma unroll
@@ -670,7 +688,7 @@ static int launch_cfg(const FwdParams& p0, hipStream_t s) {
   FwdParams p = p0;
   p.tiles = (int)((p.F + FT - 1) / FT);
   size_t lds = sizeof(float2) * G * C::LBUF + (MODE != 0 ? sizeof(float) * FT * PS : 0);
-  if (MODE == 1) {
+  if (MODE == 1 || MODE == 3) {
     // band tables ride along in LDS when two workgroups still fit a CU
     const size_t tables = sizeof(float) * (size_t)p.nnz + 3 * sizeof(int) * (size_t)p.n_mels;
     if (lds + tables <= 80 * 1024) {
@@ -683,6 +701,11 @@ static int launch_cfg(const FwdParams& p0, hipStream_t s) {
                 "LDS budget");
   const long long total = p.B * p.tiles;
   if (total <= 0) return MIA_OK;
+  if (MODE == 3 &&
+      (p.n_mels % 4 != 0 || sizeof(float) * (size_t)FT * p.n_mels > sizeof(float2) * G * C::LBUF)) {
+    set_error("frame-major mel rows do not fit this plan's FFT buffers");
+    return MIA_ERR_UNSUPPORTED;
+  }
   auto kern = fwd_kernel<C, MODE, WG, ITERS>;
   if (lds > 64 * 1024) {
     MIA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -750,6 +773,20 @@ bool fft_size_supported(int n_fft) {
   }
 }
 
+// Whether launch_forward(mode 1) can write (B, F, n_mels) rows for this plan.
+bool forward_frame_major_ok(int n_fft, int n_mels) {
+  if (n_mels % 4 != 0) return false;
+  switch (n_fft) {
+#define X(NFFT, CFG, WG, ITERS)                                                              \
+  case NFFT:                                                                                 \
+    return sizeof(float) * (size_t)(CFG::groups<WG>() * ITERS) * n_mels <=                   \
+           sizeof(float2) * (size_t)CFG::groups<WG>() * CFG::LBUF;
+    MIA_FWD_SIZES(X)
+#undef X
+    default: return false;
+  }
+}
+
 int forward_tile_frames(int n_fft, int /*mode*/) {
   switch (n_fft) {
 #define X(NFFT, CFG, WG, ITERS) \
@@ -762,7 +799,8 @@ int forward_tile_frames(int n_fft, int /*mode*/) {
 
 int launch_forward(const mia_plan* plan, const FwdParams& p, int mode, hipStream_t s) {
   if (mode == 0) return dispatch_mode<0>(plan->n_fft, p, s);
-  return mode == 1 ? dispatch_mode<1>(plan->n_fft, p, s) : dispatch_mode<2>(plan->n_fft, p, s);
+  if (mode == 1) return p.frame_major ? dispatch_mode<3>(plan->n_fft, p, s) : dispatch_mode<1>(plan->n_fft, p, s);
+  return dispatch_mode<2>(plan->n_fft, p, s);
 }
 
 }  // namespace mia
