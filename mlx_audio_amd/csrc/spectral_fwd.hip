@@ -656,28 +656,46 @@ using Cfg256 = FftCfg<256, 8, 16, 8, 1, 16>;
 using Cfg400 = FftCfg<400, 10, 20, 10, 1, 20>;
 using Cfg512 = FftCfg<512, 32, 8, 8, 4, 8>;
 using Cfg800 = FftCfg<800, 10, 20, 20, 1, 20>;
-// 1024 and 4096 points: eight points per thread and pass (four passes of radix 8 / 4, a frame
-// is one / four whole waves): half the per-thread state of a three-pass plan and no spills.
-// Measured against the three-pass plans <1024, 32, 8, 8, 8> and <4096, 128, 16, 16, 8> on one
-// box: CLAP 1.77 -> 1.56 ms, HTDemucs round trip 19.2 -> 16.0 ms.  The same shape for 2048
-// points (<2048, 128, 8, 8, 4, 8, 4>: a frame is two waves, workgroup barriers between the
-// passes) is slower than the one-wave three-pass plan (MFCC 17.2 against 14.2 ms), and capping
-// the registers for four waves per SIMD spills 25 - 90 of them and loses everywhere.
-#ifdef MIA_FWD2048_V2
-#define MIA_FWD2048_ITERS 4
-#else
-#define MIA_FWD2048_ITERS 2
+// 1024, 2048 and 4096 points: eight points per thread and pass (four passes of radix 8 / 4, a
+// frame is one / two / four whole waves): half the per-thread state of a three-pass plan.
+// What that state buys is occupancy: with 256-thread workgroups, two frames per group and tile,
+// and the register budget of THREE waves per SIMD (168 registers, no spills) instead of two,
+// CLAP went 1.54 -> 1.20 ms and MFCC 12.7 -> 11.7 ms on one box (tools/ab_w.sh); four waves per
+// SIMD spill and lose (2.15 / 22.5 ms), as do the one-wave three-pass plan for 2048 points under
+// the same budget (39 ms) and 128-thread workgroups (2.0 ms).  The smaller tile (8 / 4 frames)
+// costs nothing where the output leaves frame-major (MFCC); CLAP's rows leave in 32-byte pieces.
+// The knobs stay macros for such A/B builds (tools/build_variant.sh).
+#ifndef MIA_WG1024
+#define MIA_WG1024 256
 #endif
-using Cfg1024 = FftCfg<1024, 64, 8, 4, 4, 8, 4>;
-#ifdef MIA_FWD2048_V2
-using Cfg2048 = FftCfg<2048, 128, 8, 8, 4, 8, 4>;
-#else
-using Cfg2048 = FftCfg<2048, 64, 16, 8, 8, 16>;
+#ifndef MIA_IT1024
+#define MIA_IT1024 2
 #endif
-using Cfg4096 = FftCfg<4096, 256, 8, 8, 8, 8, 4>;
+#ifndef MIA_OCC1024
+#define MIA_OCC1024 3
+#endif
+#ifndef MIA_WG2048
+#define MIA_WG2048 256
+#endif
+#ifndef MIA_IT2048
+#define MIA_IT2048 2
+#endif
+#ifndef MIA_OCC2048
+#define MIA_OCC2048 3
+#endif
+#ifndef MIA_OCC4096
+#define MIA_OCC4096 2
+#endif
+using Cfg1024 = FftCfg<1024, 64, 8, 4, 4, 8, 4, MIA_OCC1024>;
+#ifdef MIA_FWD2048_ONE_WAVE
+using Cfg2048 = FftCfg<2048, 64, 16, 8, 8, 16, 1, MIA_OCC2048>;
+#else
+using Cfg2048 = FftCfg<2048, 128, 8, 8, 4, 8, 4, MIA_OCC2048>;
+#endif
+using Cfg4096 = FftCfg<4096, 256, 8, 8, 8, 8, 4, MIA_OCC4096>;
 #define MIA_FWD_BIG(X) \
-  X(1024, Cfg1024, 512, 2) \
-  X(2048, Cfg2048, 256, MIA_FWD2048_ITERS) \
+  X(1024, Cfg1024, MIA_WG1024, MIA_IT1024) \
+  X(2048, Cfg2048, MIA_WG2048, MIA_IT2048) \
   X(4096, Cfg4096, 256, 4)
 
 template <class C, int MODE, int WG, int ITERS>
