@@ -180,6 +180,18 @@ int mia_melspectrogram(const mia_plan* plan, const float* y, int64_t B, int64_t 
                        int per_clip, float* out, void* workspace,
                        size_t workspace_bytes, void* stream);
 
+/* The same with the result written frame-major, out: (B, F, n_mels) float32 - the layout the
+ * reference's CLAP features have ([T, F] after its transpose, models/clap/
+ * feature_extractor.py:205-212): a tile of a few frames then leaves the kernel as one contiguous
+ * run instead of n_mels short row pieces.  Served by the compiled generic kernels when
+ * n_mels % 4 == 0 (mia_mel_frames_supported(plan) == 1); other plans return
+ * MIA_ERR_UNSUPPORTED and the caller transposes. */
+int mia_mel_frames_supported(const mia_plan* plan);
+int mia_melspectrogram_frames(const mia_plan* plan, const float* y, int64_t B, int64_t T,
+                              int epilogue, float ref, float amin, float coef, float top_db,
+                              int per_clip, float* out, void* workspace,
+                              size_t workspace_bytes, void* stream);
+
 /* mia_melspectrogram for callers that cannot allocate device memory (code under HIP graph
  * capture, tight serving loops, harnesses that forbid hipMalloc): the same kernels and the
  * same result bit for bit, but the clamp keys live in a device array of the library itself

@@ -76,6 +76,10 @@ SIGNATURES = {
     "mia_melspectrogram": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_float, c_float,
                                    c_float, c_float, c_int, c_void_p, c_void_p, c_size_t,
                                    c_void_p]),
+    "mia_melspectrogram_frames": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_float, c_float,
+                                   c_float, c_float, c_int, c_void_p, c_void_p, c_size_t,
+                                   c_void_p]),
+    "mia_mel_frames_supported": (c_int, [c_void_p]),
     "mia_melspectrogram_static": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_float,
                                           c_float, c_float, c_float, c_int, c_void_p, c_void_p]),
     "mia_mfcc_workspace_bytes": (c_size_t, [c_void_p, c_int64, c_int64]),

@@ -803,13 +803,24 @@ static int forward_mel_dispatch(const mia_plan* plan, const FwdParams& p, hipStr
   return launch_forward(plan, p, 1, s);
 }
 
+static bool mel_frame_major_ok(const mia_plan* plan) {
+  return !plan->generic && plan->d_sweep_meta == nullptr &&
+         forward_frame_major_ok(plan->n_fft, plan->n_mels);
+}
+
 static int mel_forward(const mia_plan* plan, const float* y, int64_t B, int64_t T, int epilogue,
                        float ref, float amin, float coef, float top_db, int per_clip, float* out,
-                       void* workspace, size_t workspace_bytes, hipStream_t s) {
+                       void* workspace, size_t workspace_bytes, hipStream_t s, int frame_major = 0) {
   FwdParams p;
   int rc = fill_fwd(plan, y, B, T, p);
   if (rc != MIA_OK) return rc;
   MIA_REQUIRE(plan->n_mels > 0, "plan has no mel stage");
+  if (frame_major && !mel_frame_major_ok(plan)) {
+    set_error("this plan writes (B, n_mels, F) only (frame-major rows need one of the compiled "
+              "generic kernels and n_mels %% 4 == 0)");
+    return MIA_ERR_UNSUPPORTED;
+  }
+  p.frame_major = frame_major ? 1 : 0;
   MIA_REQUIRE(out != nullptr || B == 0, "null output");
   MIA_REQUIRE(epilogue >= 0 && epilogue <= 2, "bad epilogue %d", epilogue);
   p.n_mels = plan->n_mels;
@@ -870,6 +881,17 @@ int mia_melspectrogram(const mia_plan* plan, const float* y, int64_t B, int64_t 
                        void* workspace, size_t workspace_bytes, void* stream) {
   return mel_forward(plan, y, B, T, epilogue, ref, amin, coef, top_db, per_clip, out, workspace,
                      workspace_bytes, (hipStream_t)stream);
+}
+
+int mia_mel_frames_supported(const mia_plan* plan) {
+  return plan != nullptr && plan->n_mels > 0 && mel_frame_major_ok(plan) ? 1 : 0;
+}
+
+int mia_melspectrogram_frames(const mia_plan* plan, const float* y, int64_t B, int64_t T, int epilogue,
+                              float ref, float amin, float coef, float top_db, int per_clip, float* out,
+                              void* workspace, size_t workspace_bytes, void* stream) {
+  return mel_forward(plan, y, B, T, epilogue, ref, amin, coef, top_db, per_clip, out, workspace,
+                     workspace_bytes, (hipStream_t)stream, 1);
 }
 
 int mia_melspectrogram_static(const mia_plan* plan, const float* y, int64_t B, int64_t T,
@@ -979,9 +1001,7 @@ int mia_mfcc(const mia_plan* plan, const float* y, int64_t B, int64_t T, float t
   // mel kernel and the matrix-core DCT serve the plan, they go frame-major - a tile of a few
   // frames then leaves as one contiguous run of whole lines instead of n_mels short row
   // fragments (which reach memory as read-modify-write pairs), and the DCT reads whole runs.
-  const bool fm = !plan->generic && plan->d_sweep_meta == nullptr &&
-                  forward_frame_major_ok(plan->n_fft, plan->n_mels) &&
-                  dct2_frame_major_ok(plan->n_mels, plan->n_mfcc);
+  const bool fm = mel_frame_major_ok(plan) && dct2_frame_major_ok(plan->n_mels, plan->n_mfcc);
   p.frame_major = fm ? 1 : 0;
   {
     const size_t keys_bytes = 2 * align256(sizeof(int) * (size_t)(B + 1));

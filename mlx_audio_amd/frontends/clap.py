@@ -28,8 +28,8 @@ def clap_log_mel(audio, sample_rate: int = CLAP_SAMPLE_RATE, n_fft: int = CLAP_N
                  hop_length: int = CLAP_HOP_LENGTH, n_mels: int = CLAP_N_MELS) -> torch.Tensor:
     """`_compute_mel` (feature_extractor.py:193-212) for [T] or [B, T] input.
 
-    Returns dB mel features [T_frames, n_mels] / [B, T_frames, n_mels] (a
-    transposed view of the kernel's frames-contiguous output).
+    Returns dB mel features [T_frames, n_mels] / [B, T_frames, n_mels], the reference's
+    layout, written that way by the kernel (contiguous).
     """
     y = as_device_f32(audio)
     is_1d = y.dim() == 1
@@ -37,8 +37,7 @@ def clap_log_mel(audio, sample_rate: int = CLAP_SAMPLE_RATE, n_fft: int = CLAP_N
         y = y[None, :]
     out = _mel_raw(y, sample_rate, n_fft, hop_length, None, "hann", True, "constant", 2.0,
                    n_mels, CLAP_FMIN, CLAP_FMAX, True, "slaney", epilogue=_lib.EPI_DB, ref=1.0,
-                   amin=1e-10, coef=10.0, top_db=-1.0)
-    out = out.transpose(1, 2)
+                   amin=1e-10, coef=10.0, top_db=-1.0, frames_first=True)
     return out[0] if is_1d else out
 
 

@@ -84,8 +84,10 @@ def mel_filterbank(sr: int, n_fft: int, n_mels: int = DEFAULT_N_MELS, fmin: floa
 
 def _mel_raw(y2d, sr, n_fft, hop_length, win_length, window, center, pad_mode, power, n_mels,
              fmin, fmax, htk, norm, epilogue=_lib.EPI_NONE, ref=1.0, amin=1e-10, coef=10.0,
-             top_db=-1.0, per_clip=False) -> torch.Tensor:
-    """(B, T) float32 on GPU -> (B, n_mels, frames) float32 via the fused kernel."""
+             top_db=-1.0, per_clip=False, frames_first=False) -> torch.Tensor:
+    """(B, T) float32 on GPU -> (B, n_mels, frames) float32 via the fused kernel.  With
+    `frames_first` the result is (B, frames, n_mels): written that way by the kernel where the
+    plan can (contiguous), else a transposed view of the (B, n_mels, frames) result."""
     hop_length, win_length = _resolve(n_fft, hop_length, win_length)
     if center and pad_mode not in _lib.PAD_MODES:
         raise ValueError(f"Unknown pad_mode: '{pad_mode}'. Supported: reflect, constant, edge")
@@ -96,15 +98,17 @@ def _mel_raw(y2d, sr, n_fft, hop_length, win_length, window, center, pad_mode, p
     B, T = y2d.shape
     F = plan.num_frames(T)
     lib = _lib.lib()
-    out = torch.empty((B, n_mels, F), dtype=torch.float32, device=y2d.device)
+    direct = bool(frames_first) and lib.mia_mel_frames_supported(plan.handle) == 1
+    out = torch.empty((B, F, n_mels) if direct else (B, n_mels, F), dtype=torch.float32, device=y2d.device)
     ws_bytes = lib.mia_mel_workspace_bytes(plan.handle, B, T)
     ws = torch.empty((max(ws_bytes, 1),), dtype=torch.uint8, device=y2d.device)
+    entry = lib.mia_melspectrogram_frames if direct else lib.mia_melspectrogram
     with torch.cuda.device(y2d.device):
-        _lib.check(lib.mia_melspectrogram(
+        _lib.check(entry(
             plan.handle, y2d.data_ptr(), B, T, int(epilogue), float(ref), float(amin),
             float(coef), float(top_db), int(bool(per_clip)), out.data_ptr(), ws.data_ptr(),
             ws_bytes, stream_ptr(y2d.device)))
-    return out
+    return out.transpose(1, 2) if (frames_first and not direct) else out
 
 
 def melspectrogram(y, sr: int = 22050, n_fft: int = 2048, hop_length=None, win_length=None,

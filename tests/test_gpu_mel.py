@@ -287,3 +287,39 @@ def test_power_to_db_callable_ref():
     c = power_to_db(S, ref=float(S.max())).cpu().numpy()
     assert np.array_equal(a, c) and np.array_equal(b, c)
     assert abs(a.max()) < 1e-6
+
+
+@pytest.mark.parametrize("n_fft,hop,n_mels", [(1024, 480, 64), (2048, 512, 128), (512, 128, 40), (400, 100, 80),
+                                              (4096, 1024, 96), (256, 64, 32), (800, 200, 60)])
+def test_frame_major_mel_equals_transposed_mel(gpu, n_fft, hop, n_mels):
+    """mia_melspectrogram_frames writes (B, F, n_mels); the values are those of
+    mia_melspectrogram bit for bit, for the dB epilogue with a clamp and for plain mel power.
+    Plans it does not serve (the n_fft = 400 / hop 160 kernel, n_mels % 4 != 0) say so."""
+    from mlx_audio_amd import _lib
+    from mlx_audio_amd.primitives.mel import _mel_raw
+
+    g = torch.Generator(device="cuda").manual_seed(n_fft + n_mels)
+    y = torch.randn((3, 5 * n_fft + 37), device=gpu, generator=g)
+    y[1, : 2 * n_fft] *= 1e-3
+    for kw in ({"epilogue": _lib.EPI_DB, "top_db": 60.0, "per_clip": True}, {}):
+        a = _mel_raw(y, 16000, n_fft, hop, None, "hann", True, "reflect", 2.0, n_mels, 0.0, None, False,
+                     "slaney", **kw)
+        b = _mel_raw(y, 16000, n_fft, hop, None, "hann", True, "reflect", 2.0, n_mels, 0.0, None, False,
+                     "slaney", frames_first=True, **kw)
+        assert b.shape == (3, a.shape[2], n_mels) and b.is_contiguous()
+        assert torch.equal(a.transpose(1, 2), b)
+
+
+def test_frame_major_mel_unsupported_plans(gpu):
+    from mlx_audio_amd import _lib
+    from mlx_audio_amd.primitives.mel import _mel_raw
+
+    y = torch.randn((2, 16000), device=gpu)
+    # Whisper's framing is served by its own kernel: the mirror falls back to a transposed view
+    a = _mel_raw(y, 16000, 400, 160, None, "hann", True, "constant", 2.0, 80, 0.0, 8000.0, False, "slaney")
+    b = _mel_raw(y, 16000, 400, 160, None, "hann", True, "constant", 2.0, 80, 0.0, 8000.0, False, "slaney",
+                 frames_first=True)
+    assert not b.is_contiguous() and torch.equal(a.transpose(1, 2), b)
+    c = _mel_raw(y, 16000, 1024, 256, None, "hann", True, "constant", 2.0, 30, 0.0, None, False, "slaney",
+                 frames_first=True)
+    assert c.shape[2] == 30 and not c.is_contiguous()
