@@ -28,8 +28,9 @@ struct FftCfg {
   static constexpr int NPASS = 2 + (R2_ > 1) + (R3_ > 1);
   static constexpr int RL = (NPASS == 4) ? R3_ : ((NPASS == 3) ? R2_ : R1_);   // last radix
   static constexpr int NSL = M / RL;                    // stride of last pass
-  static constexpr int PADQ = PADQ_;                    // one pad slot per PADQ
-  static constexpr int LBUF = M + M / PADQ_ + 2;
+  static constexpr int PADQ = PADQ_;                    // one pad slot per PADQ; 0: XOR swizzle instead
+  static constexpr bool XORSW = PADQ_ == 0;
+  static constexpr int LBUF = XORSW ? M : M + M / (XORSW ? 1 : PADQ_) + 2;
   static constexpr bool MULTIWAVE = (T_ > 64);
   static constexpr int GPW = MULTIWAVE ? 0 : 64 / T_;   // groups per wave
   static_assert(R0_ * R1_ * R2_ * R3_ == M, "radices must multiply to n_fft/2");
@@ -56,12 +57,30 @@ struct FftCfg {
       active = lane < GPW * T_;
     }
   }
-  // LDS slot of logical element i (padding breaks power-of-two strides).
-  static __device__ __forceinline__ int pos(int i) { return i + i / PADQ; }
+  // LDS slot of logical element i.  Padding (one slot per PADQ elements) breaks the
+  // power-of-two strides of the Stockham writes but leaves the contiguous reads of a 16- or
+  // 32-lane group one slot too long for the banks (2-way on every such read).  The XOR form
+  // (bits 3..6 of the index folded into bits 0..3) is a permutation inside every 128 elements:
+  // contiguous runs stay conflict-free, the strided writes spread over all banks (a bank
+  // simulation of the four passes gives 152 LDS cycles per frame and wave against 224 with
+  // padding, 144 being conflict-free), and the buffer needs no extra slots.
+  static __device__ __forceinline__ int pos(int i) {
+    if constexpr (XORSW) {
+      return i ^ ((i >> 3) & 15);
+    } else {
+      return i + i / (XORSW ? 1 : PADQ);
+    }
+  }
   template <int S>
   static __device__ __forceinline__ int pos_strided(int j, int r) {
-    if constexpr (S % PADQ == 0) {
-      return pos(j) + r * (S + S / PADQ);
+    if constexpr (XORSW) {
+      if constexpr (S % 128 == 0) {
+        return pos(j) + r * S;  // a multiple of 128 leaves bits 0..6 alone
+      } else {
+        return pos(j + r * S);
+      }
+    } else if constexpr (S % (XORSW ? 1 : PADQ) == 0) {
+      return pos(j) + r * (S + S / (XORSW ? 1 : PADQ));
     } else {
       return pos(j + r * S);
     }
@@ -686,13 +705,25 @@ using Cfg800 = FftCfg<800, 10, 20, 20, 1, 20>;
 #ifndef MIA_OCC4096
 #define MIA_OCC4096 2
 #endif
-using Cfg1024 = FftCfg<1024, 64, 8, 4, 4, 8, 4, MIA_OCC1024>;
+// LDS layout of the FFT buffers (A/B on one box, tools/ab_w.sh): for 1024 points the compiler
+// pairs the LDS reads (ds_read2_b64: 16-lane groups over 32 banks), which a pad slot per 16
+// elements keeps conflict-free where one per 8 makes every contiguous read 2-way (CLAP 1.215 ->
+// 1.115 ms); 2048 and 4096 points read with single ds_read_b64 and prefer one per 8 (MFCC 11.75
+// against 12.0 ms).  The XOR swizzle (PADQ 0) removes nearly all conflicts in the bank
+// simulation but its address arithmetic costs more than they did (1.43 / 14.4 ms).
+#ifndef MIA_PADQ1024
+#define MIA_PADQ1024 16
+#endif
+#ifndef MIA_PADQ
+#define MIA_PADQ 8
+#endif
+using Cfg1024 = FftCfg<1024, 64, 8, 4, 4, MIA_PADQ1024, 4, MIA_OCC1024>;
 #ifdef MIA_FWD2048_ONE_WAVE
 using Cfg2048 = FftCfg<2048, 64, 16, 8, 8, 16, 1, MIA_OCC2048>;
 #else
-using Cfg2048 = FftCfg<2048, 128, 8, 8, 4, 8, 4, MIA_OCC2048>;
+using Cfg2048 = FftCfg<2048, 128, 8, 8, 4, MIA_PADQ, 4, MIA_OCC2048>;
 #endif
-using Cfg4096 = FftCfg<4096, 256, 8, 8, 8, 8, 4, MIA_OCC4096>;
+using Cfg4096 = FftCfg<4096, 256, 8, 8, 8, MIA_PADQ, 4, MIA_OCC4096>;
 #define MIA_FWD_BIG(X) \
   X(1024, Cfg1024, MIA_WG1024, MIA_IT1024) \
   X(2048, Cfg2048, MIA_WG2048, MIA_IT2048) \
