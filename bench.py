@@ -221,7 +221,7 @@ KERNEL_OF = {
     "resample": "upfirdn_kernel (polyphase FIR, input span and phase table staged in LDS)",
     "contrast": "spectral_contrast_kernel<16> (one thread per frame, sorted register arrays)",
     "demucs_front": "fwd_kernel<4096> + cac_moments_kernel + cac_normalize_kernel + row kernels",
-    "spectral_gate": "fwd_kernel<2048> + magnitude/phase + 9 mask kernels + polar + istft_own_kernel<2048>",
+    "spectral_gate": "fwd_kernel<2048> + magnitude + energy / threshold / mask kernels + gate_apply_spectrum_kernel + istft_own_kernel<2048>",
     "griffinlim": "per iteration istft_own_kernel<2048> + fwd_kernel<2048> + griffinlim_update_kernel",
     "onset": "onset_flux_shift_kernel (a wave per 64 frames, lagged values by lane shift)",
     "features_y": "fwd_kernel<2048> with the statistics epilogue (no spectrogram in memory)",

@@ -389,6 +389,15 @@ int mia_gate_mask_box(const float* mag, const float* thr, int64_t rows, int bins
  * order mia_istft reads fastest. */
 int mia_gate_apply(const float* mag, const float* mask, const float* phase, int64_t rows, int64_t bins,
                    int64_t frames, int keep, float p, int size_time, void* out, void* stream);
+/* The same steps for a caller that still holds the complex spectrum the magnitudes came from:
+ * mag * exp(i phase) is that spectrum, so out = spec * m, spec and out complex64 in
+ * (rows, frames, bins) order, mask (rows, bins, frames).  Before the time average the mask may
+ * also be averaged over size_freq bins (1: none), bit-identical to a mia_box_filter launch
+ * along the bins.  Equal to mia_gate_apply up to the rounding of its sine / cosine; no magnitude
+ * or phase planes are read. */
+int mia_gate_apply_spectrum(const void* spec, const float* mask, int64_t rows, int64_t bins,
+                            int64_t frames, int keep, float p, int size_freq, int size_time,
+                            void* out, void* stream);
 
 /* ---- HTDemucs input normalisation (models/demucs/model.py:206-233) ---------------------
  * mia_normalize_rows: per row of n floats, mean and population standard deviation, then

@@ -114,6 +114,8 @@ SIGNATURES = {
                               c_void_p, c_void_p]),
     "mia_gate_apply": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int,
                                c_float, c_int, c_void_p, c_void_p]),
+    "mia_gate_apply_spectrum": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int,
+                                        c_float, c_int, c_int, c_void_p, c_void_p]),
     "mia_gate_mask_box": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int64, c_int, c_int64,
                                   c_float, c_int, c_float, c_int, c_void_p, c_void_p]),
     "mia_mask_op": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p, c_void_p]),

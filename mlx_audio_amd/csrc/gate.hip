@@ -8,21 +8,38 @@ namespace mia {
 
 constexpr float kGateEps = 1e-8f;  // the reference's DIVISION_EPSILON
 
-// energy[row, f] = mean over bins of mag^2
-__global__ __launch_bounds__(256) void frame_energy_kernel(const float* __restrict__ mag,
-                                                           long long rows, int bins, long long F,
-                                                           float* __restrict__ energy) {
-  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= rows * F) return;
-  const long long row = g / F, f = g - row * F;
-  const float* __restrict__ col = mag + row * bins * F + f;
+// Mean of a window from its double-precision sum: one multiplication by the reciprocal a thread
+// takes once, in every kernel alike (the fused forms stay bit-identical to the separate ones).
+__device__ __forceinline__ double window_inv(int size) { return 1.0 / (double)size; }
+__device__ __forceinline__ float window_mean(double sum, double inv) { return (float)(sum * inv); }
+
+// energy[row, f] = mean over bins of mag^2.  A block takes 32 frames; eight groups of threads
+// each sum every eighth bin (one thread per frame could keep only a few hundred waves in
+// flight, each behind a chain of `bins` loads), and the eight partial sums are added in a fixed
+// order, so the result does not depend on the launch.
+__global__ __launch_bounds__(256) void frame_energy_kernel(const float* __restrict__ mag, int bins,
+                                                           long long F, float* __restrict__ energy) {
+  __shared__ float part[8][33];
+  const long long row = blockIdx.y;
+  const int fx = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const long long f = (long long)blockIdx.x * 32 + fx;
   float acc = 0.0f;
+  if (f < F) {
+    const float* __restrict__ col = mag + row * bins * F + f;
 #pragma unroll 8
-  for (int k = 0; k < bins; ++k) {
-    const float v = col[(long long)k * F];
-    acc += v * v;
+    for (int k = g; k < bins; k += 8) {
+      const float v = col[(long long)k * F];
+      acc += v * v;
+    }
   }
-  energy[g] = acc / (float)bins;
+  part[g][fx] = acc;
+  __syncthreads();
+  if (g == 0 && f < F) {
+    float sum = part[0][fx];
+#pragma unroll
+    for (int q = 1; q < 8; ++q) sum += part[q][fx];
+    energy[row * F + f] = sum / (float)bins;
+  }
 }
 
 // thr[row, bin] = mean + n_std * std (population) of mag[row, bin, idx[row, q]], q < n_sel;
@@ -86,7 +103,7 @@ __global__ __launch_bounds__(256) void box_filter_kernel(const float* __restrict
     const long long q = j < 0 ? 0 : (j >= n ? n - 1 : j);
     sum += (double)line[q * inner];
   }
-  out[g] = (float)(sum / (double)size);
+  out[g] = window_mean(sum, window_inv(size));
 }
 
 // mask = clip((mag - thr * gain) / (mag + eps), 0, 1); thr is (rows, bins, frames) or, with
@@ -125,6 +142,7 @@ __global__ __launch_bounds__(256) void gate_mask_box_kernel(const float* __restr
   if (f >= F) return;
   const unsigned k = blockIdx.y, row = blockIdx.z;
   const size_t plane = (size_t)row * bins * F;
+  const double inv = window_inv(size);
   double sum = 0.0;
   for (int j = (int)k - size / 2; j <= (int)k + (size - 1) / 2; ++j) {
     const unsigned q = j < 0 ? 0u : (j >= (int)bins ? bins - 1 : (unsigned)j);
@@ -135,7 +153,46 @@ __global__ __launch_bounds__(256) void gate_mask_box_kernel(const float* __restr
     if (keep) v = 1.0f - p * (1.0f - v);
     sum += (double)v;
   }
-  out[plane + (size_t)k * F + f] = size == 1 ? (float)sum : (float)(sum / (double)size);
+  out[plane + (size_t)k * F + f] = size == 1 ? (float)sum : window_mean(sum, inv);
+}
+
+// gate_mask_box_kernel for windows of up to kGateMaxWin bins, bit-identical to it: a block takes
+// 32 bins x 64 frames, computes the mask values of its bins and the window's halo once, in one
+// sweep of independent loads, into LDS, and sums the windows from there (the one-thread-per-
+// output form re-derives every mask value `size` times behind a chain of dependent loads).
+constexpr int kGateKT = 32, kGateFT = 64, kGateMaxWin = 33;
+__global__ __launch_bounds__(256) void gate_mask_box_tiled_kernel(
+    const float* __restrict__ mag, const float* __restrict__ thr, unsigned bins, unsigned F,
+    int per_bin, unsigned rows_thr, float gain, int keep, float p, int size,
+    float* __restrict__ out) {
+  __shared__ float vt[kGateKT + kGateMaxWin - 1][kGateFT];
+  const unsigned row = blockIdx.z;
+  const int k0 = (int)blockIdx.y * kGateKT;
+  const unsigned fx = threadIdx.x & (kGateFT - 1), ky = threadIdx.x / kGateFT;
+  const unsigned f = blockIdx.x * kGateFT + fx;
+  const unsigned fc = f < F ? f : F - 1;
+  const size_t plane = (size_t)row * bins * F;
+  const int nrows = kGateKT + size - 1;
+  const double inv = window_inv(size);
+  for (int kk = (int)ky; kk < nrows; kk += 256 / kGateFT) {
+    const int j = k0 - size / 2 + kk;
+    const unsigned q = j < 0 ? 0u : (j >= (int)bins ? bins - 1 : (unsigned)j);
+    const size_t i = plane + (size_t)q * F + fc;
+    const float t = per_bin ? thr[(rows_thr == 1 ? 0 : (size_t)row * bins) + q] : thr[i];
+    const float m = mag[i];
+    float v = fminf(fmaxf((m - t * gain) / (m + kGateEps), 0.0f), 1.0f);
+    if (keep) v = 1.0f - p * (1.0f - v);
+    vt[kk][fx] = v;
+  }
+  __syncthreads();
+  if (f >= F) return;
+  for (int kl = (int)ky; kl < kGateKT; kl += 256 / kGateFT) {
+    const unsigned k = (unsigned)(k0 + kl);
+    if (k >= bins) break;
+    double sum = 0.0;
+    for (int j = 0; j < size; ++j) sum += (double)vt[kl + j][fx];
+    out[plane + (size_t)k * F + f] = size == 1 ? (float)sum : window_mean(sum, inv);
+  }
 }
 
 // op 0: out = 1 - p (1 - a);  op 1: out = a * b
@@ -162,6 +219,7 @@ __global__ __launch_bounds__(256) void gate_apply_kernel(const float* __restrict
   const long long row = blockIdx.z;
   const long long f0 = (long long)blockIdx.x * 32, k0 = (long long)blockIdx.y * 32;
   const long long base = row * bins * F;
+  const double inv_time = window_inv(size_time);
   for (int j = threadIdx.y; j < 32; j += 8) {  // j: bin in the tile, x: frame
     const long long k = k0 + j, f = f0 + threadIdx.x;
     float2 v = {0.0f, 0.0f};
@@ -174,7 +232,7 @@ __global__ __launch_bounds__(256) void gate_apply_kernel(const float* __restrict
           const long long q = j < 0 ? 0 : (j >= F ? F - 1 : j);
           sum += (double)mask[base + k * F + q];
         }
-        m = (float)(sum / (double)size_time);
+        m = window_mean(sum, inv_time);
       }
       if (keep) m = 1.0f - p * (1.0f - m);
       const float a = mag[i] * m;
@@ -192,6 +250,125 @@ __global__ __launch_bounds__(256) void gate_apply_kernel(const float* __restrict
   }
 }
 
+// gate_apply_kernel for callers that still hold the complex spectrum: mag * exp(i phase) is the
+// spectrum itself, so out[row, f, k] = spec[row, f, k] * m(row, k, f) with the mask prepared as
+// above and, before that, optionally averaged over size_freq bins (each frequency average
+// rounded to float32 as the separate box_filter_kernel launch would store it, so the result is
+// bit-identical to that launch followed by this kernel).  The spectrum is read and written in
+// its own (rows, frames, bins) order; only the mask tile turns through LDS.  No magnitude or
+// phase planes are read and no sine / cosine is taken.
+__global__ __launch_bounds__(256) void gate_apply_spectrum_kernel(const float2* __restrict__ spec,
+                                                                  const float* __restrict__ mask,
+                                                                  long long bins, long long F,
+                                                                  int keep, float p, int size_freq,
+                                                                  int size_time,
+                                                                  float2* __restrict__ out) {
+  __shared__ float tile[32][33];
+  const long long row = blockIdx.z;
+  const long long f0 = (long long)blockIdx.x * 32, k0 = (long long)blockIdx.y * 32;
+  const long long base = row * bins * F;
+  const double inv_freq = window_inv(size_freq), inv_time = window_inv(size_time);
+  for (int j = threadIdx.y; j < 32; j += 8) {  // j: bin in the tile, x: frame
+    const long long k = k0 + j, f = f0 + threadIdx.x;
+    float m = 0.0f;
+    if (k < bins && f < F) {
+      auto over_bins = [&](long long q) {  // the mask at (k, frame q) after the frequency average
+        if (size_freq == 1) return mask[base + k * F + q];
+        double sum = 0.0;
+        for (long long j0 = k - size_freq / 2; j0 <= k + (size_freq - 1) / 2; ++j0) {
+          const long long kk = j0 < 0 ? 0 : (j0 >= bins ? bins - 1 : j0);
+          sum += (double)mask[base + kk * F + q];
+        }
+        return window_mean(sum, inv_freq);
+      };
+      if (size_time > 1) {
+        double sum = 0.0;
+        for (long long q0 = f - size_time / 2; q0 <= f + (size_time - 1) / 2; ++q0) {
+          sum += (double)over_bins(q0 < 0 ? 0 : (q0 >= F ? F - 1 : q0));
+        }
+        m = window_mean(sum, inv_time);
+      } else {
+        m = over_bins(f);
+      }
+      if (keep) m = 1.0f - p * (1.0f - m);
+    }
+    tile[j][threadIdx.x] = m;
+  }
+  __syncthreads();
+  for (int j = threadIdx.y; j < 32; j += 8) {  // j: frame in the tile, x: bin
+    const long long f = f0 + j, k = k0 + threadIdx.x;
+    if (k < bins && f < F) {
+      const long long i = base + f * bins + k;
+      const float2 v = spec[i];
+      const float m = tile[threadIdx.x][j];
+      out[i] = {v.x * m, v.y * m};
+    }
+  }
+}
+
+// gate_apply_spectrum_kernel for time windows of up to kGateMaxWin frames, bit-identical to it,
+// in two phases with one barrier, like a plain transposing copy.  Phase one: the block's patch of
+// the mask (32 bins x 32 frames plus the time window's halo), averaged over size_freq bins on the
+// way in (independent loads that hit the caches), lands in LDS with frames along the rows.
+// Phase two: each thread takes the time average of its element straight from that patch (read
+// across the rows: conflict-free with the odd pitch), applies the keep step and scales the
+// spectrum values it fetched before phase one.
+__global__ __launch_bounds__(256) void gate_apply_spectrum_tiled_kernel(
+    const float2* __restrict__ spec, const float* __restrict__ mask, long long bins, long long F,
+    int keep, float p, int size_freq, int size_time, float2* __restrict__ out) {
+  constexpr int W = 32 + kGateMaxWin - 1;  // frames of the patch at most
+  __shared__ float avg[32][W + 1];
+  const long long row = blockIdx.z;
+  const long long f0 = (long long)blockIdx.x * 32, k0 = (long long)blockIdx.y * 32;
+  const long long base = row * bins * F;
+  const int tid = threadIdx.y * 32 + threadIdx.x;
+  const int nf = 32 + size_time - 1;
+  const double inv_freq = window_inv(size_freq), inv_time = window_inv(size_time);
+  float2 sv[4];  // the thread's four spectrum values, on their way while the mask is prepared
+#pragma unroll
+  for (int jj = 0; jj < 4; ++jj) {
+    const long long f = f0 + threadIdx.y + 8 * jj, k = k0 + threadIdx.x;
+    sv[jj] = (k < bins && f < F) ? spec[base + f * bins + k] : float2{0.0f, 0.0f};
+  }
+  const unsigned magic = (unsigned)((0x100000000ULL + (unsigned)nf - 1) / (unsigned)nf);
+  for (int idx = tid; idx < 32 * nf; idx += 256) {
+    const int kl = (int)__umulhi((unsigned)idx, magic);  // idx / nf (exact: idx < 2^16)
+    const int ff = idx - kl * nf;
+    const long long fq = f0 - size_time / 2 + ff;
+    const long long fc = fq < 0 ? 0 : (fq >= F ? F - 1 : fq);
+    const long long k = k0 + kl;
+    float v;
+    if (size_freq == 1) {
+      v = mask[base + (k < bins ? k : bins - 1) * F + fc];
+    } else {
+      double sum = 0.0;
+#pragma unroll 4
+      for (long long j0 = k - size_freq / 2; j0 <= k + (size_freq - 1) / 2; ++j0) {
+        const long long kc = j0 < 0 ? 0 : (j0 >= bins ? bins - 1 : j0);
+        sum += (double)mask[base + kc * F + fc];
+      }
+      v = window_mean(sum, inv_freq);
+    }
+    avg[kl][ff] = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int jj = 0; jj < 4; ++jj) {  // frame threadIdx.y + 8 jj of the tile, x: bin
+    const int j = threadIdx.y + 8 * jj;
+    const long long f = f0 + j, k = k0 + threadIdx.x;
+    if (k < bins && f < F) {
+      float m = avg[threadIdx.x][j];
+      if (size_time > 1) {
+        double sum = 0.0;
+        for (int q = 0; q < size_time; ++q) sum += (double)avg[threadIdx.x][j + q];
+        m = window_mean(sum, inv_time);
+      }
+      if (keep) m = 1.0f - p * (1.0f - m);
+      out[base + f * bins + k] = {sv[jj].x * m, sv[jj].y * m};
+    }
+  }
+}
+
 static inline unsigned gate_blocks(long long n) { return (unsigned)((n + 255) / 256); }
 
 }  // namespace mia
@@ -204,8 +381,12 @@ int mia_frame_energy(const float* mag, int64_t rows, int bins, int64_t frames, f
   MIA_REQUIRE(rows >= 0 && bins >= 1 && frames >= 0, "rows, bins, frames must be >= 0, 1, 0");
   if (rows == 0 || frames == 0) return MIA_OK;
   MIA_REQUIRE(mag && energy, "null pointer");
-  hipLaunchKernelGGL(frame_energy_kernel, dim3(gate_blocks(rows * frames)), dim3(256), 0,
-                     (hipStream_t)stream, mag, (long long)rows, bins, (long long)frames, energy);
+  for (int64_t r0 = 0; r0 < rows; r0 += 65535) {  // a launch takes 65535 rows
+    const int64_t nr = rows - r0 < 65535 ? rows - r0 : 65535;
+    hipLaunchKernelGGL(frame_energy_kernel, dim3((unsigned)((frames + 31) / 32), (unsigned)nr),
+                       dim3(256), 0, (hipStream_t)stream, mag + (size_t)r0 * bins * frames, bins,
+                       (long long)frames, energy + (size_t)r0 * frames);
+  }
   MIA_CHECK_HIP(hipGetLastError());
   return MIA_OK;
 }
@@ -298,6 +479,15 @@ int mia_gate_mask_box(const float* mag, const float* thr, int64_t rows, int bins
     }
     return MIA_OK;
   }
+  if (size_freq <= kGateMaxWin) {
+    const dim3 tgrid((unsigned)((frames + kGateFT - 1) / kGateFT),
+                     (unsigned)((bins + kGateKT - 1) / kGateKT), (unsigned)rows);
+    hipLaunchKernelGGL(gate_mask_box_tiled_kernel, tgrid, dim3(256), 0, (hipStream_t)stream, mag, thr,
+                       (unsigned)bins, (unsigned)frames, per_bin, (unsigned)rows_thr, gain, keep, p,
+                       size_freq, out);
+    MIA_CHECK_HIP(hipGetLastError());
+    return MIA_OK;
+  }
   const dim3 grid((unsigned)((frames + 255) / 256), (unsigned)bins, (unsigned)rows);
   hipLaunchKernelGGL(gate_mask_box_kernel, grid, dim3(256), 0, (hipStream_t)stream, mag, thr,
                      (unsigned)rows, (unsigned)bins, (unsigned)frames, per_bin, (unsigned)rows_thr,
@@ -327,6 +517,33 @@ int mia_gate_apply(const float* mag, const float* mask, const float* phase, int6
   hipLaunchKernelGGL(gate_apply_kernel, grid, dim3(32, 8), 0, (hipStream_t)stream, mag, mask, phase,
                      (long long)bins, (long long)frames, keep, p, size_time, (float2*)out);
   MIA_CHECK_HIP(hipGetLastError());
+  return MIA_OK;
+}
+
+int mia_gate_apply_spectrum(const void* spec, const float* mask, int64_t rows, int64_t bins,
+                            int64_t frames, int keep, float p, int size_freq, int size_time,
+                            void* out, void* stream) {
+  using namespace mia;
+  MIA_REQUIRE(rows >= 0 && bins >= 0 && frames >= 0 && size_freq >= 1 && size_time >= 1,
+              "negative shape or size");
+  if (rows == 0 || bins == 0 || frames == 0) return MIA_OK;
+  MIA_REQUIRE(spec && mask && out, "null pointer");
+  MIA_REQUIRE((bins + 31) / 32 <= 65535, "too many bins for one launch");
+  for (int64_t r0 = 0; r0 < rows; r0 += 65535) {  // a launch takes 65535 rows
+    const int64_t nr = rows - r0 < 65535 ? rows - r0 : 65535;
+    const size_t off = (size_t)r0 * bins * frames;
+    const dim3 grid((unsigned)((frames + 31) / 32), (unsigned)((bins + 31) / 32), (unsigned)nr);
+    if (size_time <= kGateMaxWin) {
+      hipLaunchKernelGGL(gate_apply_spectrum_tiled_kernel, grid, dim3(32, 8), 0, (hipStream_t)stream,
+                         (const float2*)spec + off, mask + off, (long long)bins, (long long)frames,
+                         keep, p, size_freq, size_time, (float2*)out + off);
+    } else {
+      hipLaunchKernelGGL(gate_apply_spectrum_kernel, grid, dim3(32, 8), 0, (hipStream_t)stream,
+                         (const float2*)spec + off, mask + off, (long long)bins, (long long)frames,
+                         keep, p, size_freq, size_time, (float2*)out + off);
+    }
+    MIA_CHECK_HIP(hipGetLastError());
+  }
   return MIA_OK;
 }
 

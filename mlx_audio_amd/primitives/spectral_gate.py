@@ -3,8 +3,9 @@
 
 The reference computes the STFT on its array library, moves magnitude and phase to the host,
 builds the gate mask in NumPy / scipy.ndimage and goes back for the inverse STFT.  Here every
-step stays on the GPU; the only host work is choosing the quietest tenth of the frames (a sort
-of one number per frame, done with NumPy as in the reference).
+step stays on the GPU, the choice of the quietest tenth of the frames included (a stable device
+sort of one number per frame), and the phase is never taken apart: magnitude * exp(i phase) is
+the spectrum itself, so the gated spectrum is the STFT scaled by the mask.
 """
 
 from __future__ import annotations
@@ -14,7 +15,7 @@ import torch
 
 from .. import _lib
 from .._runtime import as_device_f32, stream_ptr
-from .stft import istft, magnitude, phase, stft
+from .stft import istft, magnitude, stft
 
 
 def _validate(n_fft, hop_length, prop_decrease) -> None:
@@ -98,6 +99,20 @@ class _Ops:
                   frames, int(bool(keep)), float(prop_decrease), int(size_time), out.data_ptr())
         return out.transpose(1, 2)
 
+    def apply_spectrum(self, spec, mask, keep, prop_decrease, size_time=1, size_freq=1):
+        """apply() from the complex (rows, bins, frames) spectrum the magnitudes were taken of
+        (mag * exp(i ph) is that spectrum): spec * mask', same layout as apply()'s result; the
+        mask may be averaged over size_freq bins before its time average, in the same launch."""
+        rows, bins, frames = mask.shape
+        rows_first = spec.transpose(1, 2)   # stft() hands out a view of (rows, frames, bins) rows
+        if not rows_first.is_contiguous():
+            rows_first = rows_first.contiguous()
+        out = torch.empty((rows, frames, bins), dtype=torch.complex64, device=self.dev)
+        self._run("mia_gate_apply_spectrum", rows_first.data_ptr(), mask.data_ptr(), rows, bins,
+                  frames, int(bool(keep)), float(prop_decrease), int(size_freq), int(size_time),
+                  out.data_ptr())
+        return out.transpose(1, 2)
+
     def mask_box(self, mag, thr, gain, keep, prop_decrease, size_freq):
         """mask(), optionally keep(), and the moving average over size_freq bins in one launch."""
         rows, bins, frames = mag.shape
@@ -107,18 +122,21 @@ class _Ops:
                   float(prop_decrease), int(size_freq), out.data_ptr())
         return out
 
-    def gate(self, mag, ph, thr, gain, steps, keep_first, prop_decrease):
+    def gate(self, mag, spec, thr, gain, steps, keep_first, prop_decrease):
         """The mask pipeline with its first frequency average folded into the mask kernel and
-        its last time average folded into the closing kernel.  steps: [(axis, size), ...] with
-        axis "f" or "t", sizes > 1; keep_first: the keep step comes before the averages (the
-        adaptive variant) instead of after them."""
+        its last time average folded into the closing kernel, which scales the spectrum `spec`
+        the magnitudes came from.  steps: [(axis, size), ...] with axis "f" or "t", sizes > 1;
+        keep_first: the keep step comes before the averages (the adaptive variant) instead of
+        after them."""
         steps = list(steps)
         first = steps.pop(0)[1] if steps and steps[0][0] == "f" else 1
         last = steps.pop()[1] if steps and steps[-1][0] == "t" else 1
         mask = self.mask_box(mag, thr, gain, keep_first, prop_decrease, first)
+        # a frequency average right before the closing kernel's time average rides along in it
+        last_freq = steps.pop()[1] if steps and steps[-1][0] == "f" else 1
         for axis, size in steps:
             mask = self.box(mask, size, 1) if axis == "f" else self.box(mask, 1, size)
-        return self.apply(mag, mask, ph, not keep_first, prop_decrease, last)
+        return self.apply_spectrum(spec, mask, not keep_first, prop_decrease, last, last_freq)
 
     def times(self, a, b):
         out = self.new(a.shape)
@@ -146,7 +164,7 @@ def spectral_gate(audio, noise_profile=None, *, sr: int = 22050, n_fft: int = 20
     n_samples = x.shape[-1]
     kw = dict(n_fft=n_fft, hop_length=hop_length, win_length=win_length, window=window, center=True)
     C = stft(x, **kw)   # magnitude / phase transpose it to (rows, bins, frames) as they go
-    mag, ph = magnitude(C), phase(C)
+    mag = magnitude(C)
     ops = _Ops(mag.device)
     rows, bins, frames = mag.shape
 
@@ -157,10 +175,9 @@ def spectral_gate(audio, noise_profile=None, *, sr: int = 22050, n_fft: int = 20
             raise ValueError(f"noise_profile has {noise_mag.shape[0]} rows, the audio {rows}")
         thr = ops.noise_threshold(noise_mag, None, n_std_thresh)
     elif stationary:
-        energy = ops.frame_energy(mag).cpu().numpy()
         n_quiet = max(1, int(0.1 * frames))
-        quiet = np.stack([np.argsort(energy[b])[:n_quiet] for b in range(rows)]).astype(np.int32)
-        thr = ops.noise_threshold(mag, torch.from_numpy(quiet).to(mag.device), n_std_thresh)
+        order = torch.sort(ops.frame_energy(mag), dim=1, stable=True).indices
+        thr = ops.noise_threshold(mag, order[:, :n_quiet].to(torch.int32).contiguous(), n_std_thresh)
     else:
         tc_frames = max(1, int(time_constant_s * sr / hop_length))
         thr = ops.time_min(mag, tc_frames)
@@ -176,7 +193,7 @@ def spectral_gate(audio, noise_profile=None, *, sr: int = 22050, n_fft: int = 20
     if n_grad_freq > 1 or n_grad_time > 1:
         steps += [("f", int(n_grad_freq)), ("t", int(n_grad_time))]
     steps = [(a, n) for a, n in steps if n > 1]
-    enhanced = ops.gate(mag, ph, thr, gain, steps, False, prop_decrease)
+    enhanced = ops.gate(mag, C, thr, gain, steps, False, prop_decrease)
     y = istft(enhanced, hop_length=hop_length, win_length=win_length, window=window, center=True,
               length=n_samples)
     return y[0] if is_1d else y
@@ -198,10 +215,10 @@ def spectral_gate_adaptive(audio, *, sr: int = 22050, n_fft: int = 2048, hop_len
         x = x[None]
     n_samples = x.shape[-1]
     C = stft(x, n_fft=n_fft, hop_length=hop_length, center=True)
-    mag, ph = magnitude(C), phase(C)
+    mag = magnitude(C)
     ops = _Ops(mag.device)
     floor = ops.time_min(mag, ahead + back + 1)
-    enhanced = ops.gate(mag, ph, floor, 1.0 + 10 ** (threshold_db / 20.0), [("f", 3), ("t", 5)],
+    enhanced = ops.gate(mag, C, floor, 1.0 + 10 ** (threshold_db / 20.0), [("f", 3), ("t", 5)],
                         True, prop_decrease)
     y = istft(enhanced, hop_length=hop_length, center=True, length=n_samples)
     return y[0] if is_1d else y

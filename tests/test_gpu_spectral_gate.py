@@ -78,6 +78,25 @@ def test_mask_building_blocks(gpu):
         want = (mag * mm * np.exp(1j * ph.astype(np.float64))).astype(np.complex64)
         np.testing.assert_allclose(got.cpu().numpy(), want, rtol=0, atol=2e-6)
 
+    # the spectrum form: mag * exp(i ph) handed over as the complex spectrum itself
+    spec = (mag * np.exp(1j * ph.astype(np.float64))).astype(np.complex64)
+    spec_d = _dev(spec.transpose(0, 2, 1), gpu).transpose(1, 2)   # a view of (rows, frames, bins) rows
+    for keep, pd, size in ((True, 0.8, 1), (False, 1.0, 1), (True, 0.9, 4), (False, 1.0, 150)):
+        got = ops.apply_spectrum(spec_d, m, keep, pd, size)
+        assert got.shape == mag.shape and got.transpose(1, 2).is_contiguous()
+        np.testing.assert_allclose(got.cpu().numpy(), ops.apply(d, m, _dev(ph, gpu), keep, pd, size).cpu().numpy(),
+                                   rtol=0, atol=2e-6)
+        mb = ops.box(m, 1, size).cpu().numpy()
+        mm = 1.0 - pd * (1.0 - mb) if keep else mb
+        if keep:   # the keep step contracts to one fused multiply-add on the device
+            np.testing.assert_allclose(got.cpu().numpy(), spec * mm.astype(np.float32), rtol=1e-6, atol=1e-7)
+        else:
+            np.testing.assert_array_equal(got.cpu().numpy(), spec * mm.astype(np.float32))
+    np.testing.assert_array_equal(ops.apply_spectrum(_dev(spec, gpu), m, False, 1.0).cpu().numpy(), spec * mk)
+    for sf, st in ((2, 4), (9, 1), (3, 5), (70, 2)):   # a frequency average folded in: bit-identical
+        assert torch.equal(ops.apply_spectrum(spec_d, m, True, 0.7, st, sf),
+                           ops.apply_spectrum(spec_d, ops.box(m, sf, 1), True, 0.7, st))
+
 
 def test_whole_mask_matches_the_oracle(gpu):
     """gate_mask of the oracle against the same sequence of launches on identical magnitudes."""
@@ -142,6 +161,10 @@ def test_behaviour_and_c_abi_checks(gpu):
     assert lib.mia_mask_op(a.data_ptr(), 0, 48, 2, 0.0, o.data_ptr(), s) == _lib.MIA_ERR_INVALID
     assert lib.mia_noise_threshold(a.data_ptr(), 2, 4, 0, 0, 0, 1.0, o.data_ptr(), s) == _lib.MIA_ERR_INVALID
     assert lib.mia_frame_energy(a.data_ptr(), 0, 4, 6, o.data_ptr(), s) == _lib.MIA_OK
+    assert lib.mia_gate_apply_spectrum(a.data_ptr(), a.data_ptr(), 1, 4, 3, 0, 1.0, 0, 1, o.data_ptr(), s) == _lib.MIA_ERR_INVALID
+    assert lib.mia_gate_apply_spectrum(a.data_ptr(), a.data_ptr(), 1, 4, 3, 0, 1.0, 1, 0, o.data_ptr(), s) == _lib.MIA_ERR_INVALID
+    assert lib.mia_gate_apply_spectrum(0, a.data_ptr(), 1, 4, 3, 0, 1.0, 1, 1, o.data_ptr(), s) == _lib.MIA_ERR_INVALID
+    assert lib.mia_gate_apply_spectrum(0, 0, 0, 4, 3, 0, 1.0, 1, 1, 0, s) == _lib.MIA_OK
 
 
 def test_full_size_batch(gpu):
