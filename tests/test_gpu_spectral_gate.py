@@ -98,6 +98,32 @@ def test_mask_building_blocks(gpu):
                            ops.apply_spectrum(spec_d, ops.box(m, sf, 1), True, 0.7, st))
 
 
+@pytest.mark.parametrize("shape", [(1, 3, 2), (2, 1, 1), (1, 33, 31), (2, 32, 64), (1, 70, 5)])
+def test_tiled_kernels_on_small_and_ragged_shapes(gpu, shape):
+    """Windows wider than the array, single bins / frames, tiles cut by both edges: the LDS-tiled
+    mask and closing kernels against SciPy's filters and against the one-thread-per-output forms
+    (window 40 takes those)."""
+    rng = np.random.default_rng(sum(shape))
+    mag = np.abs(rng.standard_normal(shape)).astype(np.float32)
+    thr = np.abs(rng.standard_normal(shape[:2])).astype(np.float32)
+    spec = (rng.standard_normal(shape) + 1j * rng.standard_normal(shape)).astype(np.complex64)
+    ops = _Ops(gpu)
+    d, t = _dev(mag, gpu), _dev(thr, gpu)
+    spec_d = _dev(spec.transpose(0, 2, 1), gpu).transpose(1, 2)
+    base = np.clip((mag - thr[:, :, None] * 0.3) / (mag + 1e-8), 0.0, 1.0)
+    for size in (1, 2, 9, 33, 40):
+        got = ops.mask_box(d, t, 0.3, False, 1.0, size).cpu().numpy()
+        np.testing.assert_allclose(got, uniform_filter(base, size=(1, size, 1), mode="nearest"), rtol=0, atol=1e-6)
+        assert torch.equal(ops.mask_box(d, t, 0.3, True, 0.6, size), ops.box(ops.keep(ops.mask(d, t, 0.3), 0.6), size, 1))
+    m = ops.mask(d, t, 0.3)
+    for sf, st in ((1, 1), (2, 4), (9, 33), (33, 2), (1, 40), (40, 3)):
+        got = ops.apply_spectrum(spec_d, m, False, 1.0, st, sf)
+        want = spec * uniform_filter(uniform_filter(base, size=(1, sf, 1), mode="nearest"),
+                                     size=(1, 1, st), mode="nearest")
+        np.testing.assert_allclose(got.cpu().numpy(), want, rtol=0, atol=3e-6 * max(1.0, np.abs(spec).max()))
+        assert torch.equal(got, ops.apply_spectrum(spec_d, ops.box(ops.box(m, sf, 1), 1, st), False, 1.0))
+
+
 def test_whole_mask_matches_the_oracle(gpu):
     """gate_mask of the oracle against the same sequence of launches on identical magnitudes."""
     rng = np.random.default_rng(2)
