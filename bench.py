@@ -227,8 +227,8 @@ KERNEL_OF = {
     "features_y": "fwd_kernel<2048> with the statistics epilogue (no spectrogram in memory)",
     "features_all": "spectral_stat_kernel, all four statistics in two passes over the bins",
     "features": "spectral_stat_kernel x 4 (one thread per frame, bins walked in order)",
-    "resample_fft": "stockham_pass_kernel<16> x 22 + chirp / spectrum kernels (two chirp-z "
-                    "convolutions per clip)",
+    "resample_fft": "stockham_super_kernel x 4 (661 500 = 900 x 735 and 240 000 = 500 x 480 points, two "
+                    "super-passes each through LDS) + resize_packed_kernel + unpack_real_kernel",
 }
 
 

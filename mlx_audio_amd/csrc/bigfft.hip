@@ -195,6 +195,181 @@ __global__ __launch_bounds__(256) void stockham_any_kernel(const float2* __restr
   }
 }
 
+// ---------------------------------------------------------------------------
+// Super-passes: one Stockham pass of a composite radix R = r0 r1 r2 (each factor a butterfly
+// of at most 16 points, R <= 1024) whose inner structure runs in LDS, so that a row of
+// 661 500 points takes two trips through memory instead of four.  To the outside a super-pass
+// is exactly the radix-R pass of stockham_any_kernel: super-butterfly u < D = L / R reads
+// in[u + c D], c < R, multiplies by exp(-2 pi i m c / (Ns R)), m = u mod Ns, and writes
+// X[k] to out[(u - m) R + m + k Ns].  A workgroup takes kSuperW adjacent super-butterflies
+// (their elements are adjacent in memory on the way in and, past the first pass, on the way
+// out) and keeps them interleaved in LDS, element c of sequence w at [c kSuperW + w]; the
+// R-point transforms are in-place decimation steps (each butterfly reads and writes its own
+// slots, a barrier between steps), which leave X[k0 + r0 k1 + r0 r1 k2] at slot
+// k0 r1 r2 + k1 r2 + k2; the store phase reads the slots in that order.  Inner twiddles come
+// from an LDS table of exp(-2 pi i j / R) the workgroup builds once (double-precision
+// sincospi); the outer ones from a double recurrence per thread, as in the single passes.
+// ---------------------------------------------------------------------------
+constexpr int kSuperW = 16;          // adjacent super-butterflies per workgroup (128-byte runs)
+constexpr int kSuperMaxR = 1024;     // LDS: R (kSuperW + 1) complex numbers
+constexpr int kSuperThreads = 512;
+constexpr int kSuperBatch = 8;       // loads a thread has in flight before it uses the first
+constexpr unsigned long long kSuperGrid = 1024;  // workgroups per launch, about: each walks rows
+
+struct SuperPass {
+  int R;      // r[0] * r[1] * r[2]
+  int r[3];   // unused factors are 1
+  // ceil(2^32 / d) for d = r[0], r[1], r[1] * r[2], r[2], R: __umulhi(x, magic) == x / d for
+  // x < 65536 and those d (x d < 2^32), which covers every index in the kernel
+  unsigned magic_r0, magic_r1, magic_s0, magic_s1, magic_R;
+};
+static unsigned super_magic(int d) { return (unsigned)((0x100000000ULL + (unsigned)d - 1) / (unsigned)d); }
+
+// One in-place decimation step of radix R_ over the interleaved sequences: butterflies j <
+// nbf per sequence, elements S apart (magic_S divides by S); outputs k >= 1 are multiplied by
+// table[lo * k * mul].
+template <int R_>
+__device__ __forceinline__ void super_step(float2* __restrict__ buf, const float2* __restrict__ table,
+                                           int nbf, int S, unsigned magic_S, int mul) {
+  const int w = threadIdx.x % kSuperW;
+  for (int j = threadIdx.x / kSuperW; j < nbf; j += kSuperThreads / kSuperW) {
+    const int hi = S > 1 ? (int)__umulhi((unsigned)j, magic_S) : j;
+    const int lo = j - hi * S;
+    float2* __restrict__ e = buf + (size_t)(hi * (R_ * S) + lo) * kSuperW + w;
+    float2 v[R_];
+#pragma unroll
+    for (int q = 0; q < R_; ++q) v[q] = e[(size_t)q * S * kSuperW];
+    Dft<R_>::run(v);
+    if (S > 1) {
+      const int step = lo * mul;
+#pragma unroll
+      for (int k = 1; k < R_; ++k) v[k] = cmulf(v[k], table[step * k]);
+    }
+#pragma unroll
+    for (int q = 0; q < R_; ++q) e[(size_t)q * S * kSuperW] = v[q];
+  }
+}
+
+__device__ __forceinline__ void super_step_any(int radix, float2* __restrict__ buf,
+                                               const float2* __restrict__ table, int nbf, int S,
+                                               unsigned magic_S, int mul) {
+  switch (radix) {
+#define MIA_STEP(RR) case RR: super_step<RR>(buf, table, nbf, S, magic_S, mul); break;
+    MIA_STEP(16) MIA_STEP(15) MIA_STEP(14) MIA_STEP(12) MIA_STEP(10) MIA_STEP(9) MIA_STEP(8)
+    MIA_STEP(7) MIA_STEP(6) MIA_STEP(5) MIA_STEP(4) MIA_STEP(3) MIA_STEP(2)
+#undef MIA_STEP
+    default: break;
+  }
+}
+
+// The elements c0, c0 + CSTEP, ... < R of one sequence, D apart, into registers.
+template <int PER, int CSTEP>
+__device__ __forceinline__ void super_fetch(float2 (&v)[PER], const float2* __restrict__ src, bool live,
+                                            int c0, int R, unsigned D) {
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int c = c0 + i * CSTEP;
+    v[i] = (live && c < R) ? src[(size_t)c * D] : float2{0.0f, 0.0f};
+  }
+}
+
+__global__ __launch_bounds__(kSuperThreads, 1) void stockham_super_kernel(
+    const float2* __restrict__ in, float2* __restrict__ out, unsigned L, unsigned Ns, long long rows,
+    SuperPass sp, unsigned blocks_u, unsigned per_xcd, unsigned row_slots) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char super_smem[];
+  float2* buf = reinterpret_cast<float2*>(super_smem);   // [R][kSuperW]
+  float2* table = buf + (size_t)sp.R * kSuperW;          // [R]
+  const int R = sp.R, r0 = sp.r[0], r1 = sp.r[1], r2 = sp.r[2];
+  const unsigned D = L / (unsigned)R;
+  // Workgroups are dealt to the eight XCDs in turn, each with its own L2.  The 128-byte runs
+  // of neighbouring blocks of super-butterflies share cache lines (rows and strides are not
+  // multiples of a line), so XCD x takes the contiguous blocks [x per_xcd, (x + 1) per_xcd) of
+  // a row, one after the other: the shared lines are fetched, and the partial lines written,
+  // within one L2.
+  const unsigned xcd = blockIdx.x & 7u, seq = blockIdx.x >> 3;
+  const unsigned row_slot = seq / per_xcd;
+  const unsigned block_u = xcd * per_xcd + (seq - row_slot * per_xcd);
+  if (block_u >= blocks_u) return;
+  const unsigned u0 = block_u * kSuperW;
+  const int tid = threadIdx.x;
+  for (int j = tid; j < R; j += kSuperThreads) {
+    double sn, cs;
+    sincospi(-2.0 * (double)j / (double)R, &sn, &cs);
+    table[j] = {(float)cs, (float)sn};
+  }
+  // load phase: thread = (sequence w, elements c = c0, c0 + cstep, ...)
+  const int w = tid % kSuperW, c0 = tid / kSuperW;
+  constexpr int cstep = kSuperThreads / kSuperW;
+  constexpr int kPer = kSuperMaxR / cstep;  // elements per thread at most
+  const unsigned u = u0 + (unsigned)w;
+  const bool live = u < D;
+  const unsigned m = live ? u % Ns : 0u;
+  double wr0 = 1.0, wi0 = 0.0, sr = 1.0, si = 0.0;  // exp(-2 pi i m c0 / (Ns R)) and the step by cstep
+  if (Ns > 1) {
+    const double den = (double)Ns * (double)R;
+    sincospi(-2.0 * ((double)m * (double)c0) / den, &wi0, &wr0);
+    sincospi(-2.0 * ((double)m * (double)cstep) / den, &si, &sr);
+  }
+  // store phase: past the first pass the kSuperW sequences are adjacent in memory for every k;
+  // in the first pass (Ns == 1) a sequence's R outputs are, so there the lanes run along k
+  const bool along_k = Ns < (unsigned)kSuperW;
+  for (long long row = row_slot; row < rows; row += row_slots) {
+    float2* __restrict__ dst = out + (size_t)row * L;
+    __syncthreads();  // the previous row's store phase is done with buf (and the table is built)
+    {
+      const float2* __restrict__ src = in + (size_t)row * L + u;
+      double wr = wr0, wi = wi0;
+      constexpr int kBatch = kPer < kSuperBatch ? kPer : kSuperBatch;
+      for (int cb = c0; cb < R; cb += cstep * kBatch) {
+        float2 v[kBatch];
+        super_fetch<kBatch, cstep>(v, src, live, cb, R, D);
+#pragma unroll
+        for (int i = 0; i < kBatch; ++i) {
+          const int c = cb + i * cstep;
+          if (c < R) {
+            float2 x = v[i];
+            if (Ns > 1) x = cmulf(x, float2{(float)wr, (float)wi});
+            buf[(size_t)c * kSuperW + w] = x;
+          }
+          const double nr = wr * sr - wi * si;
+          wi = wr * si + wi * sr;
+          wr = nr;
+        }
+      }
+    }
+    __syncthreads();
+    super_step_any(r0, buf, table, R / r0, r1 * r2, sp.magic_s0, 1);
+    if (r1 > 1) {
+      __syncthreads();
+      super_step_any(r1, buf, table, R / r1, r2, sp.magic_s1, r0);
+    }
+    if (r2 > 1) {
+      __syncthreads();
+      super_step_any(r2, buf, table, R / r2, 1, 0u, 0);
+    }
+    __syncthreads();
+    const int total = R * kSuperW;
+    for (int idx = tid; idx < total; idx += kSuperThreads) {
+      int ws, k;
+      if (along_k) {
+        ws = (int)__umulhi((unsigned)idx, sp.magic_R);
+        k = idx - ws * R;
+      } else {
+        k = idx / kSuperW;
+        ws = idx - k * kSuperW;
+      }
+      const unsigned us = u0 + (unsigned)ws;
+      if (us >= D) continue;
+      const int t = (int)__umulhi((unsigned)k, sp.magic_r0), k0 = k - t * r0;
+      const int k2 = (int)__umulhi((unsigned)t, sp.magic_r1), k1 = t - k2 * r1;
+      const int slot = (k0 * r1 + k1) * r2 + k2;
+      // not along k: ws is this thread's own w
+      const unsigned ms = along_k ? (Ns == 1 ? 0u : us % Ns) : m;
+      dst[(size_t)(us - ms) * R + ms + (size_t)k * Ns] = buf[(size_t)slot * kSuperW + ws];
+    }
+  }
+}
+
 // Bin kk (0 <= kk <= Nh) of the length-N real transform from the length-Nh transform Z of the
 // packed row: X = E + w^kk O, E = (Z[kk] + conj Z[Nh-kk])/2, O = -i (Z[kk] - conj Z[Nh-kk])/2.
 __device__ __forceinline__ float2 real_bin(const float2* __restrict__ Z, long long Nh, long long kk) {
@@ -202,9 +377,12 @@ __device__ __forceinline__ float2 real_bin(const float2* __restrict__ Z, long lo
   const float2 bz = Z[kk == 0 ? 0 : Nh - kk];
   const float2 E = {0.5f * (a.x + bz.x), 0.5f * (a.y - bz.y)};
   const float2 O = {0.5f * (a.y + bz.y), -0.5f * (a.x - bz.x)};
-  double s, c;
-  sincospi(-(double)kk / (double)Nh, &s, &c);  // exp(-2 pi i kk / N), N = 2 Nh
-  const float2 wO = cmulf(O, float2{(float)c, (float)s});
+  // exp(-2 pi i kk / N), N = 2 Nh: the quotient in double, its sine and cosine in float (the
+  // quotient's rounding to float moves the angle by at most 1e-7 rad, one float rounding of the
+  // twiddle; the double-precision sincospi was most of this kernel's time)
+  float s, c;
+  sincospif((float)(-(double)kk / (double)Nh), &s, &c);
+  const float2 wO = cmulf(O, float2{c, s});
   return {E.x + wO.x, E.y + wO.y};
 }
 
@@ -232,9 +410,9 @@ __global__ void resize_packed_kernel(const float2* __restrict__ Zin, long long N
   const float2 B = bin(Mh - k);
   const float2 S = {A.x + B.x, A.y - B.y};  // A + conj B
   const float2 D = {A.x - B.x, A.y + B.y};  // A - conj B
-  double s, c;
-  sincospi((double)k / (double)Mh, &s, &c);  // exp(+2 pi i k / M), M = 2 Mh
-  const float2 wD = cmulf(D, float2{(float)c, (float)s});
+  float s, c;
+  sincospif((float)((double)k / (double)Mh), &s, &c);  // exp(+2 pi i k / M), M = 2 Mh
+  const float2 wD = cmulf(D, float2{c, s});
   // Z' = S + i wD;  store conj(Z')
   Zout[g] = {S.x - wD.y, -(S.y + wD.x)};
 }
@@ -284,6 +462,90 @@ static int plan_radices(long long L, int* radices) {
   limit = plan_search(L, cand, n_cand, 0, 0, limit + 1, cur, radices, &best_sum, 0);
   return radices[0] ? limit : 0;
 }
+// Super-pass plan of length L: the fewest radices R_i <= kSuperMaxR, each a product of at most
+// three butterflies of at most 16 points and leaving at least kSuperW super-butterflies per row
+// (L / R_i >= kSuperW), that multiply to L; among those the plan whose largest radix is
+// smallest (LDS per workgroup).  Returns the number of passes, 0 if there is none.
+#ifndef MIA_FFT_SUPERPASS
+#define MIA_FFT_SUPERPASS 1
+#endif
+static const int kSuperSub[] = {16, 15, 14, 12, 10, 9, 8, 7, 6, 5, 4, 3, 2};
+static bool super_split(int R, SuperPass* sp) {
+  const int n = (int)(sizeof(kSuperSub) / sizeof(kSuperSub[0]));
+  auto is_sub = [&](int v) {
+    for (int i = 0; i < n; ++i) {
+      if (kSuperSub[i] == v) return true;
+    }
+    return false;
+  };
+  sp->R = R;
+  if (is_sub(R)) {
+    sp->r[0] = R;
+    sp->r[1] = sp->r[2] = 1;
+    return true;
+  }
+  for (int i = 0; i < n; ++i) {  // two factors, the larger first
+    const int a = kSuperSub[i];
+    if (R % a == 0 && R / a <= a && is_sub(R / a)) {
+      sp->r[0] = a;
+      sp->r[1] = R / a;
+      sp->r[2] = 1;
+      return true;
+    }
+  }
+  for (int i = 0; i < n; ++i) {
+    for (int j = i; j < n; ++j) {
+      const int a = kSuperSub[i], b = kSuperSub[j];
+      if (R % (a * b) == 0 && R / (a * b) <= b && is_sub(R / (a * b))) {
+        sp->r[0] = a;
+        sp->r[1] = b;
+        sp->r[2] = R / (a * b);
+        return true;
+      }
+    }
+  }
+  return false;
+}
+static void super_search(long long rest, const int* cand, int n_cand, int first, int depth, int* cur,
+                         int* best, int* best_n, int* best_max, int cur_max) {
+  if (rest == 1) {
+    if (depth < *best_n || (depth == *best_n && cur_max < *best_max)) {
+      for (int i = 0; i < depth; ++i) best[i] = cur[i];
+      *best_n = depth;
+      *best_max = cur_max;
+    }
+    return;
+  }
+  if (depth + 1 > *best_n) return;
+  for (int i = first; i < n_cand; ++i) {
+    if (rest % cand[i]) continue;
+    cur[depth] = cand[i];
+    super_search(rest / cand[i], cand, n_cand, i, depth + 1, cur, best, best_n, best_max,
+                 cand[i] > cur_max ? cand[i] : cur_max);
+  }
+}
+static int plan_super(long long L, SuperPass* passes, int max_passes) {
+  if (!MIA_FFT_SUPERPASS || L < 2LL * kSuperW) return 0;
+  int cand[512], n_cand = 0;
+  const long long cap = L / kSuperW < kSuperMaxR ? L / kSuperW : kSuperMaxR;
+  for (int R = (int)cap; R >= 2 && n_cand < 512; --R) {
+    SuperPass sp;
+    if (L % R == 0 && super_split(R, &sp)) cand[n_cand++] = R;
+  }
+  int cur[8], best[8], best_n = max_passes + 1, best_max = 1 << 30;
+  super_search(L, cand, n_cand, 0, 0, cur, best, &best_n, &best_max, 0);
+  if (best_n > max_passes) return 0;
+  for (int i = 0; i < best_n; ++i) {
+    SuperPass& q = passes[i];
+    super_split(best[i], &q);
+    q.magic_r0 = super_magic(q.r[0]);
+    q.magic_r1 = super_magic(q.r[1]);
+    q.magic_s0 = super_magic(q.r[1] * q.r[2]);
+    q.magic_s1 = super_magic(q.r[2]);
+    q.magic_R = super_magic(q.R);
+  }
+  return best_n;
+}
 static bool direct_ok(long long n_in, long long n_out) {
   int r[32];
   if (n_in % 2 || n_out % 2) return false;
@@ -306,6 +568,38 @@ static int fft_any(const float2* in, float2* bufA, float2* bufB, long long L, lo
   float2* dst = bufA;
   unsigned Ns = 1;
   const unsigned gy = (unsigned)(rows < 32768 ? rows : 32768);
+  // Two super-passes instead of four or more single ones, for rows long enough that both
+  // composite radices are large: measured on 64 x 30 s rows, 661 500 -> 240 000 points
+  // 1.13 -> 0.98 ms and half the HBM traffic.  Shorter rows (any-length STFT frames, a 10 s
+  // clip) and lengths that need three super-passes run faster on the single passes: few
+  // super-butterflies per row leave the 16-sequence workgroups part empty, and a third trip
+  // through LDS costs more than the pass it saves.
+  SuperPass sp[4];
+  const int n_super = (n >= 4 && L >= 200000) ? plan_super(L, sp, 2) : 0;
+  if (n_super > 0) {
+    for (int i = 0; i < n_super; ++i) {
+      const size_t lds = sizeof(float2) * (size_t)sp[i].R * (kSuperW + 1);
+      if (lds > 64 * 1024) {
+        MIA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(stockham_super_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      }
+      const unsigned D = (unsigned)(L / sp[i].R);
+      // keep the grid around the size of the device when there are many rows: a workgroup
+      // builds its twiddle table once and walks rows
+      const unsigned gx = (D + kSuperW - 1) / kSuperW;
+      unsigned gys = gy;
+      while (gys > 1 && (unsigned long long)gx * gys > kSuperGrid) gys = (gys + 1) / 2;
+      const unsigned per_xcd = (gx + 7) / 8;
+      hipLaunchKernelGGL(stockham_super_kernel, dim3(8 * per_xcd * gys), dim3(kSuperThreads), lds, s,
+                         src, dst, (unsigned)L, Ns, rows, sp[i], gx, per_xcd, gys);
+      MIA_CHECK_HIP(hipGetLastError());
+      Ns *= (unsigned)sp[i].R;
+      src = dst;
+      dst = dst == bufA ? bufB : bufA;
+    }
+    *result = src;
+    return MIA_OK;
+  }
   for (int i = 0; i < n; ++i) {
     const int R = radices[i];
     const dim3 grid((unsigned)((L / R + 255) / 256), gy);

@@ -131,7 +131,9 @@ FFT_TOL = 2e-6  # of the row's peak: float32 FFT round-off (SciPy's own float32 
 
 FFT_SIZES = [(1, 3), (2, 3), (3, 2), (2, 1), (7, 5), (16, 8), (8, 16), (17, 16), (441, 160),
              (160, 441), (1000, 999), (1001, 1000), (4410, 1600), (44100, 16000),
-             (100003, 36283), (65536, 32768), (32768, 65536)]
+             (100003, 36283), (65536, 32768), (32768, 65536),
+             # rows long enough for the two-super-pass plans (halves 220 500, 240 000, 661 500)
+             (441000, 160000), (480000, 441000), (1323000, 480000)]
 
 
 @pytest.mark.parametrize("n,m", FFT_SIZES)
