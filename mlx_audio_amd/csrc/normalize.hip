@@ -33,13 +33,24 @@ __global__ __launch_bounds__(256) void row_moments_kernel(const float* __restric
                                                           double* __restrict__ sums) {
   const long long row = blockIdx.y;
   const float* __restrict__ line = x + row * n;
-  double s = 0.0, q = 0.0;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-    const double v = (double)line[i];
-    s += v;
-    q += v * v;
+  // four independent partial sums per thread: four loads in flight instead of a chain of one
+  double s4[4] = {0.0, 0.0, 0.0, 0.0}, q4[4] = {0.0, 0.0, 0.0, 0.0};
+  const long long stride = (long long)gridDim.x * 256;
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  for (; i + 3 * stride < n; i += 4 * stride) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const double v = (double)line[i + k * stride];
+      s4[k] += v;
+      q4[k] += v * v;
+    }
   }
-  block_accumulate(s, q, sums + 2 * row);
+  for (; i < n; i += stride) {
+    const double v = (double)line[i];
+    s4[0] += v;
+    q4[0] += v * v;
+  }
+  block_accumulate((s4[0] + s4[1]) + (s4[2] + s4[3]), (q4[0] + q4[1]) + (q4[2] + q4[3]), sums + 2 * row);
 }
 
 // the same over the complex elements spec[b, c, f, t] (strides in complex elements), both
@@ -88,38 +99,50 @@ __global__ __launch_bounds__(256) void row_normalize_kernel(const float* __restr
   }
 }
 
-// out[b, 2c + part, f, t] = (part of spec[b, c, f, t] - mean_b) / (std_b + eps); 32 x 32 tiles
-// of (f, t) go through LDS: read with f fastest, written with t fastest.  grid (tiles_t,
-// tiles_f, B*C), block (32, 8).
+// out[b, 2c + part, f, t] = (part of spec[b, c, f, t] - mean_b) / (std_b + eps); tiles of 32
+// bins x 64 frames go through LDS: read with f fastest (256-byte runs of complex values), written
+// with t fastest (256-byte runs of each plane).  grid (tiles_t, tiles_f, B*C), block (32, 8).
+// Mean and 1 / (std + eps) come from one thread per workgroup (a double-precision division and
+// square root per thread would cost more than the tile's arithmetic).
+constexpr int kCacTT = 64;
 __global__ __launch_bounds__(256) void cac_normalize_kernel(const float2* __restrict__ spec, int C,
                                                             long long F, long long T, long long sb,
                                                             long long sc, long long sf, long long st,
                                                             const double* __restrict__ sums,
                                                             float eps, float* __restrict__ out,
                                                             float* __restrict__ stats) {
-  __shared__ float2 tile[32][33];
+  __shared__ float2 tile[kCacTT][33];
+  __shared__ float mean_inv[2];
   const long long bc = blockIdx.z, b = bc / C, c = bc - b * C;
-  float mean, inv;
-  mean_std(sums + 2 * b, 2.0 * (double)C * (double)F * (double)T, eps, mean, inv);
-  if (c == 0 && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && threadIdx.y == 0) {
-    stats[2 * b] = mean;
-    stats[2 * b + 1] = 1.0f / inv;
+  if (threadIdx.x == 0 && threadIdx.y == 0) {
+    float mean, inv;
+    mean_std(sums + 2 * b, 2.0 * (double)C * (double)F * (double)T, eps, mean, inv);
+    mean_inv[0] = mean;
+    mean_inv[1] = inv;
+    if (c == 0 && blockIdx.x == 0 && blockIdx.y == 0) {
+      stats[2 * b] = mean;
+      stats[2 * b + 1] = 1.0f / inv;
+    }
   }
-  const long long f0 = (long long)blockIdx.y * 32, t0 = (long long)blockIdx.x * 32;
+  const long long f0 = (long long)blockIdx.y * 32, t0 = (long long)blockIdx.x * kCacTT;
   const float2* __restrict__ src = spec + b * sb + c * sc;
-  for (int j = threadIdx.y; j < 32; j += 8) {  // j: frame within the tile, x: bin
+#pragma unroll
+  for (int j = threadIdx.y; j < kCacTT; j += 8) {  // j: frame within the tile, x: bin
     const long long f = f0 + threadIdx.x, t = t0 + j;
     float2 z = {0.0f, 0.0f};
     if (f < F && t < T) z = src[f * sf + t * st];
     tile[j][threadIdx.x] = z;
   }
   __syncthreads();
+  const float mean = mean_inv[0], inv = mean_inv[1];
   float* __restrict__ re = out + ((b * 2 * C + 2 * c) * F) * T;
   float* __restrict__ im = re + F * T;
-  for (int j = threadIdx.y; j < 32; j += 8) {  // j: bin within the tile, x: frame
-    const long long f = f0 + j, t = t0 + threadIdx.x;
+  const int tx = threadIdx.y % 2 * 32 + threadIdx.x;  // frame within the tile: 64 per bin row
+#pragma unroll
+  for (int j = threadIdx.y / 2; j < 32; j += 4) {  // j: bin within the tile
+    const long long f = f0 + j, t = t0 + tx;
     if (f < F && t < T) {
-      const float2 z = tile[threadIdx.x][j];
+      const float2 z = tile[tx][j];
       re[f * T + t] = (z.x - mean) * inv;
       im[f * T + t] = (z.y - mean) * inv;
     }
@@ -191,7 +214,7 @@ int mia_normalize_cac(const void* spec, int64_t batch, int channels, int64_t bin
                      (const float2*)spec, channels, (long long)bins, (long long)frames,
                      (long long)stride_b, (long long)stride_c, (long long)stride_f,
                      (long long)stride_t, (double*)sums);
-  const dim3 grid((unsigned)((frames + 31) / 32), (unsigned)((bins + 31) / 32),
+  const dim3 grid((unsigned)((frames + kCacTT - 1) / kCacTT), (unsigned)((bins + 31) / 32),
                   (unsigned)(batch * channels));
   MIA_REQUIRE(grid.y <= 65535, "too many bins");
   hipLaunchKernelGGL(cac_normalize_kernel, grid, dim3(32, 8), 0, s, (const float2*)spec, channels,
