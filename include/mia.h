@@ -414,6 +414,19 @@ int mia_normalize_rows(const float* x, int64_t rows, int64_t n, float eps, float
 int mia_normalize_cac(const void* spec, int64_t batch, int channels, int64_t bins, int64_t frames,
                       int64_t stride_b, int64_t stride_c, int64_t stride_f, int64_t stride_t,
                       float eps, float* out, float* stats, void* sums, void* stream);
+/* The two halves of mia_normalize_cac for a caller that computes the spectrum itself:
+ * mia_stft_moments is mia_stft that also adds up, per group of `group` consecutive rows (a
+ * batch item's channels), the sum and the sum of squares of the real and imaginary parts of
+ * bins < bins_counted of frames [frame_lo, frame_hi) - the part of the spectrum HTDemucs keeps
+ * (model.py:378-417) - into sums: device (B / group, 2) doubles, zeroed by the call (compiled FFT
+ * sizes only, MIA_ERR_UNSUPPORTED otherwise).  mia_normalize_cac_sums is mia_normalize_cac
+ * with those sums given instead of computed: no second pass over the spectrum. */
+int mia_stft_moments(const mia_plan* plan, const float* y, int64_t B, int64_t T, float scale, void* out,
+                     int group, int bins_counted, int64_t frame_lo, int64_t frame_hi, void* sums,
+                     void* stream);
+int mia_normalize_cac_sums(const void* spec, int64_t batch, int channels, int64_t bins, int64_t frames,
+                           int64_t stride_b, int64_t stride_c, int64_t stride_f, int64_t stride_t,
+                           float eps, float* out, float* stats, const void* sums, void* stream);
 
 /* ---- Whisper encoder stem (models/whisper/layers/encoder.py:72-109) ----------------------
  * What AudioEncoder.__call__ does before its transformer blocks: x = mel^T (frames, n_mels);

@@ -121,6 +121,10 @@ SIGNATURES = {
     "mia_mask_op": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p, c_void_p]),
     "mia_normalize_rows": (c_int, [c_void_p, c_int64, c_int64, c_float, c_void_p, c_void_p, c_void_p,
                                    c_void_p]),
+    "mia_stft_moments": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_float, c_void_p, c_int, c_int,
+                                 c_int64, c_int64, c_void_p, c_void_p]),
+    "mia_normalize_cac_sums": (c_int, [c_void_p, c_int64, c_int, c_int64, c_int64, c_int64, c_int64,
+                                       c_int64, c_int64, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mia_normalize_cac": (c_int, [c_void_p, c_int64, c_int, c_int64, c_int64, c_int64, c_int64,
                                   c_int64, c_int64, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mia_spectrum_part": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_void_p]),

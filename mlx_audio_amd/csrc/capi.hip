@@ -650,6 +650,34 @@ int mia_stft(const mia_plan* plan, const float* y, int64_t B, int64_t T, float s
   return launch_forward(plan, p, 0, (hipStream_t)stream);
 }
 
+int mia_stft_moments(const mia_plan* plan, const float* y, int64_t B, int64_t T, float scale, void* out,
+                     int group, int bins_counted, int64_t frame_lo, int64_t frame_hi, void* sums,
+                     void* stream) {
+  FwdParams p;
+  int rc = fill_fwd(plan, y, B, T, p);
+  if (rc != MIA_OK) return rc;
+  MIA_REQUIRE(group >= 1 && B % group == 0, "the %lld rows do not split into groups of %d",
+              (long long)B, group);
+  MIA_REQUIRE(bins_counted >= 0 && bins_counted <= plan->n_fft / 2 + 1 && frame_lo >= 0 &&
+                  frame_lo <= frame_hi,
+              "bins_counted must be in [0, n_fft/2 + 1] and 0 <= frame_lo <= frame_hi");
+  if (plan->generic) {
+    set_error("n_fft=%d has no compiled kernel: run mia_stft_ws and mia_normalize_cac", plan->n_fft);
+    return MIA_ERR_UNSUPPORTED;
+  }
+  if (B == 0) return MIA_OK;
+  MIA_REQUIRE(out && sums, "null pointer");
+  MIA_CHECK_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 2 * (size_t)(B / group), (hipStream_t)stream));
+  p.scale = scale;
+  p.cout = reinterpret_cast<float2*>(out);
+  p.mom_sums = reinterpret_cast<double*>(sums);
+  p.mom_group = group;
+  p.mom_bins = bins_counted;
+  p.mom_f_lo = frame_lo;
+  p.mom_f_hi = frame_hi;
+  return launch_forward(plan, p, 5, (hipStream_t)stream);
+}
+
 size_t mia_stft_workspace_bytes(const mia_plan* plan, int64_t B, int64_t T) {
   if (!plan || !plan->generic || B <= 0) return 0;
   const int64_t F = mia_plan_num_frames(plan, T);

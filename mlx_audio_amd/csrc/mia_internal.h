@@ -139,6 +139,12 @@ struct FwdParams {
   int* clip_max_key;   // B (+1) keys of the per-clip maximum, or nullptr
   int* clip_min_key;   // B keys of the per-clip minimum of the stored values
   int frame_major;     // generic mel kernel: write (B, F, n_mels) rows instead of (B, n_mels, F)
+  // moments epilogue (launch_forward mode 5): besides storing the spectrum, the sum and the sum
+  // of squares of the real and imaginary parts of bins < mom_bins of frames [mom_f_lo, mom_f_hi)
+  // are added to mom_sums[2 * (row / mom_group)] and [... + 1] (double, one atomic pair per tile)
+  double* mom_sums;
+  int mom_group, mom_bins;
+  long long mom_f_lo, mom_f_hi;
   int dbg;
   // spectral-statistics epilogue (epi == kEpiStats): centroid, bandwidth, roll-off, flatness
   const float* freq;   // bin frequencies

@@ -113,6 +113,7 @@ __global__ __launch_bounds__(256) void cac_normalize_kernel(const float2* __rest
                                                             float* __restrict__ stats) {
   __shared__ float2 tile[kCacTT][33];
   __shared__ float mean_inv[2];
+  if ((long long)blockIdx.x * kCacTT >= T) return;  // padding of the grid (see the launch)
   const long long bc = blockIdx.z, b = bc / C, c = bc - b * C;
   if (threadIdx.x == 0 && threadIdx.y == 0) {
     float mean, inv;
@@ -183,9 +184,9 @@ int mia_normalize_rows(const float* x, int64_t rows, int64_t n, float eps, float
   return MIA_OK;
 }
 
-int mia_normalize_cac(const void* spec, int64_t batch, int channels, int64_t bins, int64_t frames,
-                      int64_t stride_b, int64_t stride_c, int64_t stride_f, int64_t stride_t,
-                      float eps, float* out, float* stats, void* sums, void* stream) {
+static int normalize_cac(const void* spec, int64_t batch, int channels, int64_t bins, int64_t frames,
+                         int64_t stride_b, int64_t stride_c, int64_t stride_f, int64_t stride_t,
+                         float eps, float* out, float* stats, void* sums, int have_sums, void* stream) {
   using namespace mia;
   MIA_REQUIRE(batch >= 0 && channels >= 1 && bins >= 1 && frames >= 1,
               "batch, channels, bins, frames must be >= 0, 1, 1, 1");
@@ -196,32 +197,52 @@ int mia_normalize_cac(const void* spec, int64_t batch, int channels, int64_t bin
     const int64_t per = 65535 / channels;
     for (int64_t b0 = 0; b0 < batch; b0 += per) {
       const int64_t nb = batch - b0 < per ? batch - b0 : per;
-      const int rc = mia_normalize_cac((const float2*)spec + (size_t)b0 * stride_b, nb, channels, bins,
-                                       frames, stride_b, stride_c, stride_f, stride_t, eps,
-                                       out + (size_t)b0 * 2 * channels * bins * frames,
-                                       stats + 2 * (size_t)b0, (double*)sums + 2 * (size_t)b0, stream);
+      const int rc = normalize_cac((const float2*)spec + (size_t)b0 * stride_b, nb, channels, bins,
+                                   frames, stride_b, stride_c, stride_f, stride_t, eps,
+                                   out + (size_t)b0 * 2 * channels * bins * frames,
+                                   stats + 2 * (size_t)b0, (double*)sums + 2 * (size_t)b0, have_sums,
+                                   stream);
       if (rc != MIA_OK) return rc;
     }
     return MIA_OK;
   }
   hipStream_t s = (hipStream_t)stream;
-  MIA_CHECK_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 2 * (size_t)batch, s));
-  long long chunks = frames;
-  const long long cap = 2048 / (batch * channels) > 1 ? 2048 / (batch * channels) : 1;
-  if (chunks > cap) chunks = cap;
-  hipLaunchKernelGGL(cac_moments_kernel, dim3((unsigned)chunks, (unsigned)(batch * channels)),
-                     dim3(256), 0, s,
-                     (const float2*)spec, channels, (long long)bins, (long long)frames,
-                     (long long)stride_b, (long long)stride_c, (long long)stride_f,
-                     (long long)stride_t, (double*)sums);
-  const dim3 grid((unsigned)((frames + kCacTT - 1) / kCacTT), (unsigned)((bins + 31) / 32),
-                  (unsigned)(batch * channels));
+  if (!have_sums) {
+    MIA_CHECK_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 2 * (size_t)batch, s));
+    long long chunks = frames;
+    const long long cap = 2048 / (batch * channels) > 1 ? 2048 / (batch * channels) : 1;
+    if (chunks > cap) chunks = cap;
+    hipLaunchKernelGGL(cac_moments_kernel, dim3((unsigned)chunks, (unsigned)(batch * channels)),
+                       dim3(256), 0, s,
+                       (const float2*)spec, channels, (long long)bins, (long long)frames,
+                       (long long)stride_b, (long long)stride_c, (long long)stride_f,
+                       (long long)stride_t, (double*)sums);
+  }
+  // grid.x is padded to a multiple of 8 (the extra workgroups leave at once): workgroups go to
+  // the eight XCDs in turn, and with that the tiles above and below one another - which share
+  // the cache lines their 256-byte runs of a spectrum row straddle - sit behind one L2
+  const unsigned tiles_t = (unsigned)((frames + kCacTT - 1) / kCacTT);
+  const dim3 grid((tiles_t + 7) / 8 * 8, (unsigned)((bins + 31) / 32), (unsigned)(batch * channels));
   MIA_REQUIRE(grid.y <= 65535, "too many bins");
   hipLaunchKernelGGL(cac_normalize_kernel, grid, dim3(32, 8), 0, s, (const float2*)spec, channels,
                      (long long)bins, (long long)frames, (long long)stride_b, (long long)stride_c,
                      (long long)stride_f, (long long)stride_t, (const double*)sums, eps, out, stats);
   MIA_CHECK_HIP(hipGetLastError());
   return MIA_OK;
+}
+
+int mia_normalize_cac(const void* spec, int64_t batch, int channels, int64_t bins, int64_t frames,
+                      int64_t stride_b, int64_t stride_c, int64_t stride_f, int64_t stride_t,
+                      float eps, float* out, float* stats, void* sums, void* stream) {
+  return normalize_cac(spec, batch, channels, bins, frames, stride_b, stride_c, stride_f, stride_t, eps,
+                       out, stats, sums, 0, stream);
+}
+
+int mia_normalize_cac_sums(const void* spec, int64_t batch, int channels, int64_t bins, int64_t frames,
+                           int64_t stride_b, int64_t stride_c, int64_t stride_f, int64_t stride_t,
+                           float eps, float* out, float* stats, const void* sums, void* stream) {
+  return normalize_cac(spec, batch, channels, bins, frames, stride_b, stride_c, stride_f, stride_t, eps,
+                       out, stats, const_cast<void*>(sums), 1, stream);
 }
 
 }  // extern "C"

@@ -299,6 +299,7 @@ __global__ __launch_bounds__(WG, C::OCC) void fwd_kernel(FwdParams p) {
   };
 
   for (long long idx = first; idx < last; ++idx) {
+  double mom_s = 0.0, mom_q = 0.0;  // MODE 5: this thread's share of the tile's moments
   const long long b = idx / p.tiles;
   const int tile = (int)(idx - b * p.tiles);
   const long long f0 = (long long)tile * FT;
@@ -468,12 +469,20 @@ __global__ __launch_bounds__(WG, C::OCC) void fwd_kernel(FwdParams p) {
       // (frames past the end exist only in plans whose groups span waves; they took part
       // in the passes for the barriers' sake and produce nothing)
       if (!valid) continue;
-      float2* __restrict__ crow = MODE == 0 ? p.cout + (b * p.F + f) * (long long)(M + 1) : nullptr;
+      float2* __restrict__ crow = (MODE == 0 || MODE == 5) ? p.cout + (b * p.F + f) * (long long)(M + 1) : nullptr;
+      const bool mom_frame = MODE == 5 && f >= p.mom_f_lo && f < p.mom_f_hi;
       float* __restrict__ prow = P + fl * PS;
       const float half_scale = 0.5f * p.scale;
       auto emit = [&](int k, float2 X) {
         if constexpr (MODE == 0) {
           crow[k] = {X.x * half_scale, X.y * half_scale};
+        } else if constexpr (MODE == 5) {
+          const float2 z = {X.x * half_scale, X.y * half_scale};
+          crow[k] = z;
+          if (mom_frame && k < p.mom_bins) {
+            mom_s += (double)z.x + (double)z.y;
+            mom_q += (double)z.x * (double)z.x + (double)z.y * (double)z.y;
+          }
         } else {
           float pw = 0.25f * (X.x * X.x + X.y * X.y);
           if (p.power_mode == 1) pw = sqrtf(pw);
@@ -505,6 +514,31 @@ __global__ __launch_bounds__(WG, C::OCC) void fwd_kernel(FwdParams p) {
     }
   }
 
+  if constexpr (MODE == 5) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      mom_s += __shfl_xor(mom_s, off);
+      mom_q += __shfl_xor(mom_q, off);
+    }
+    __shared__ double mom_red[2][WG / 64];
+    if ((tid & 63) == 0) {
+      mom_red[0][tid >> 6] = mom_s;
+      mom_red[1][tid >> 6] = mom_q;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      double s = mom_red[0][0], q = mom_red[1][0];
+#pragma unroll
+      for (int w = 1; w < WG / 64; ++w) {
+        s += mom_red[0][w];
+        q += mom_red[1][w];
+      }
+      double* __restrict__ dst = p.mom_sums + 2 * (b / p.mom_group);
+      atomicAdd(dst, s);
+      atomicAdd(dst + 1, q);
+    }
+    __syncthreads();  // the next tile reuses the slots
+  }
   if constexpr (MODE == 2) {
     __syncthreads();
     const long long frem2 = p.F - f0;
@@ -736,7 +770,8 @@ static int launch_cfg(const FwdParams& p0, hipStream_t s) {
   constexpr int PS = (C::M + 1) | 1;
   FwdParams p = p0;
   p.tiles = (int)((p.F + FT - 1) / FT);
-  size_t lds = sizeof(float2) * G * C::LBUF + (MODE != 0 ? sizeof(float) * FT * PS : 0);
+  constexpr bool TILE = MODE != 0 && MODE != 5;  // modes that keep a power / magnitude tile
+  size_t lds = sizeof(float2) * G * C::LBUF + (TILE ? sizeof(float) * FT * PS : 0);
   if (MODE == 1 || MODE == 3) {
     // band tables ride along in LDS when two workgroups still fit a CU
     const size_t tables = sizeof(float) * (size_t)p.nnz + 3 * sizeof(int) * (size_t)p.n_mels;
@@ -745,7 +780,7 @@ static int launch_cfg(const FwdParams& p0, hipStream_t s) {
       p.lds_tables = 1;
     }
   }
-  static_assert(sizeof(float2) * G * C::LBUF + (MODE != 0 ? sizeof(float) * FT * PS : 0) <=
+  static_assert(sizeof(float2) * G * C::LBUF + (TILE ? sizeof(float) * FT * PS : 0) <=
                     160 * 1024,
                 "LDS budget");
   const long long total = p.B * p.tiles;
@@ -848,6 +883,7 @@ int forward_tile_frames(int n_fft, int /*mode*/) {
 
 int launch_forward(const mia_plan* plan, const FwdParams& p, int mode, hipStream_t s) {
   if (mode == 0) return dispatch_mode<0>(plan->n_fft, p, s);
+  if (mode == 5) return dispatch_mode<5>(plan->n_fft, p, s);
   if (mode == 1) return p.frame_major ? dispatch_mode<3>(plan->n_fft, p, s) : dispatch_mode<1>(plan->n_fft, p, s);
   return dispatch_mode<2>(plan->n_fft, p, s);
 }

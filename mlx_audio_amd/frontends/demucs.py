@@ -8,8 +8,9 @@ import math
 import torch
 
 from .. import _lib
-from .._runtime import as_device_f32, stream_ptr
+from .._runtime import as_device_f32, get_plan, stream_ptr
 from ..primitives.stft import _istft_raw, _stft_raw
+from ..primitives.windows import padded_window_np
 
 DEMUCS_N_FFT = 4096      # reference constants/audio_processing.py:15-17
 DEMUCS_HOP_LENGTH = 1024
@@ -23,15 +24,37 @@ def htdemucs_spec(x, n_fft: int = DEMUCS_N_FFT, hop_length: int = DEMUCS_HOP_LEN
     kernel's store), Nyquist bin dropped, frames [2 : 2+le] kept.  The result
     is a strided view of the kernel's (B*C, frames, bins) output.
     """
+    return _spec_and_sums(x, n_fft, hop_length, False)[0]
+
+
+def _spec_and_sums(x, n_fft: int, hop_length: int, want_sums: bool):
+    """htdemucs_spec, and with want_sums (compiled FFT sizes) the per-item sums the input
+    normalisation needs - sum and sum of squares of the real and imaginary parts of the kept
+    bins and frames - accumulated by the STFT kernel while the spectrum is still in registers.
+    Returns (spec, sums or None)."""
     x = as_device_f32(x, ndim_allowed=(3,))
     B, C, T = x.shape
     le = int(math.ceil(T / hop_length))
     pad = hop_length // 2 * 3
     xp = torch.nn.functional.pad(x, (pad, pad + le * hop_length - T))
-    raw = _stft_raw(xp.reshape(B * C, -1), n_fft, hop_length, n_fft, "hann", True, "reflect",
-                    scale=1.0 / math.sqrt(n_fft))          # (B*C, frames, bins)
+    scale = 1.0 / math.sqrt(n_fft)
+    lib = _lib.lib()
+    sums = None
+    if want_sums and lib.mia_fft_size_supported(n_fft):
+        rows = xp.reshape(B * C, -1)
+        plan = get_plan(x.device, n_fft, hop_length, True, "reflect", padded_window_np("hann", n_fft, n_fft))
+        frames = plan.num_frames(rows.shape[1])
+        raw = torch.empty((B * C, frames, n_fft // 2 + 1), dtype=torch.complex64, device=x.device)
+        sums = torch.empty((B, 2), dtype=torch.float64, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.mia_stft_moments(plan.handle, rows.data_ptr(), B * C, rows.shape[1], scale,
+                                            raw.data_ptr(), C, n_fft // 2, 2, 2 + le, sums.data_ptr(),
+                                            stream_ptr(x.device)))
+    else:
+        raw = _stft_raw(xp.reshape(B * C, -1), n_fft, hop_length, n_fft, "hann", True, "reflect",
+                        scale=scale)                       # (B*C, frames, bins)
     spec = raw.transpose(1, 2)[:, :-1, 2:2 + le]           # (B*C, n_fft//2, le)
-    return spec.unflatten(0, (B, C))
+    return spec.unflatten(0, (B, C)), sums
 
 
 def htdemucs_ispec(m, length: int, n_fft: int = DEMUCS_N_FFT,
@@ -69,8 +92,9 @@ def htdemucs_normalize(mix, spec=None, eps: float = 1e-5):
     reference, where they are used later to undo the normalisation (model.py:349, 367).
     """
     mix = as_device_f32(mix, ndim_allowed=(3,))
+    spec_sums = None
     if spec is None:
-        spec = htdemucs_spec(mix)
+        spec, spec_sums = _spec_and_sums(mix, DEMUCS_N_FFT, DEMUCS_HOP_LENGTH, True)
     if spec.dim() != 4 or spec.dtype != torch.complex64:
         raise ValueError("spec must be a complex64 [B, C, F, Tf] tensor")
     B, C, T = mix.shape
@@ -86,9 +110,14 @@ def htdemucs_normalize(mix, spec=None, eps: float = 1e-5):
         stream = stream_ptr(dev)
         sb, sc, sf, st = spec.stride()
         base = spec.data_ptr()
-        _lib.check(lib.mia_normalize_cac(base, B, Cs, F, Tf, sb, sc, sf, st, float(eps),
-                                         freq_in.data_ptr(), s_stats.data_ptr(), sums.data_ptr(),
-                                         stream))
+        if spec_sums is not None:   # the STFT kernel already added the item's sums up
+            _lib.check(lib.mia_normalize_cac_sums(base, B, Cs, F, Tf, sb, sc, sf, st, float(eps),
+                                                  freq_in.data_ptr(), s_stats.data_ptr(),
+                                                  spec_sums.data_ptr(), stream))
+        else:
+            _lib.check(lib.mia_normalize_cac(base, B, Cs, F, Tf, sb, sc, sf, st, float(eps),
+                                             freq_in.data_ptr(), s_stats.data_ptr(), sums.data_ptr(),
+                                             stream))
         _lib.check(lib.mia_normalize_rows(mix.data_ptr(), B, C * T, float(eps), mix_norm.data_ptr(),
                                           m_stats.data_ptr(), sums.data_ptr(), stream))
     return (freq_in, s_stats[:, 0].reshape(B, 1, 1, 1), s_stats[:, 1].reshape(B, 1, 1, 1),

@@ -35,9 +35,45 @@ def test_normalisation_of_mix_and_spectrogram(gpu, B, C, T):
     flat = freq_in.reshape(B, -1)
     assert flat.mean(dim=1).abs().max().item() < 1e-4
     assert (flat.std(dim=1, unbiased=False) - 1).abs().max().item() < 1e-3
-    # the default computes the spectrogram itself
+    # the default computes the spectrogram itself, with the sums added up by the STFT kernel
+    # (another order of double-precision additions: equal to float rounding of mean and std)
     again = htdemucs_normalize(md)
-    assert torch.equal(again[0], freq_in)
+    for a, g in zip(again, got):
+        np.testing.assert_allclose(a.cpu().numpy(), g.cpu().numpy(), rtol=1e-6, atol=1e-6)
+
+
+def test_stft_with_moments(gpu):
+    """mia_stft_moments: the spectrum equals mia_stft's bit for bit, the sums equal a double-
+    precision sum over the kept bins and frames, per group of rows."""
+    from mlx_audio_amd._runtime import get_plan, stream_ptr
+    from mlx_audio_amd.primitives.windows import padded_window_np
+
+    lib = _lib.lib()
+    rng = np.random.default_rng(3)
+    s = stream_ptr(gpu)
+    for n_fft, hop, rows, group, T in ((4096, 1024, 4, 2, 50000), (1024, 256, 6, 3, 9000), (512, 128, 2, 1, 3000)):
+        y = _dev((rng.standard_normal((rows, T)) * (1 + np.arange(rows))[:, None]).astype(np.float32), gpu)
+        plan = get_plan(gpu, n_fft, hop, True, "reflect", padded_window_np("hann", n_fft, n_fft))
+        F = plan.num_frames(T)
+        shape = (rows, F, n_fft // 2 + 1)
+        ref = torch.empty(shape, dtype=torch.complex64, device=gpu)
+        out = torch.empty(shape, dtype=torch.complex64, device=gpu)
+        sums = torch.full((rows // group, 2), 7.0, dtype=torch.float64, device=gpu)   # the call zeroes them
+        _lib.check(lib.mia_stft(plan.handle, y.data_ptr(), rows, T, 0.25, ref.data_ptr(), s))
+        lo, hi, nb = 2, F - 1, n_fft // 2
+        _lib.check(lib.mia_stft_moments(plan.handle, y.data_ptr(), rows, T, 0.25, out.data_ptr(), group, nb,
+                                        lo, hi, sums.data_ptr(), s))
+        assert torch.equal(torch.view_as_real(out), torch.view_as_real(ref))
+        kept = torch.view_as_real(ref[:, lo:hi, :nb]).to(torch.float64).reshape(rows // group, -1)
+        np.testing.assert_allclose(sums[:, 0].cpu().numpy(), kept.sum(dim=1).cpu().numpy(), rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(sums[:, 1].cpu().numpy(), (kept * kept).sum(dim=1).cpu().numpy(), rtol=1e-11)
+    assert lib.mia_stft_moments(plan.handle, y.data_ptr(), 2, 3000, 1.0, out.data_ptr(), 3, 10, 0, 1,
+                                sums.data_ptr(), s) == _lib.MIA_ERR_INVALID     # 2 rows, groups of 3
+    assert lib.mia_stft_moments(plan.handle, y.data_ptr(), 2, 3000, 1.0, out.data_ptr(), 1, 999, 0, 1,
+                                sums.data_ptr(), s) == _lib.MIA_ERR_INVALID     # more bins than the plan has
+    odd = get_plan(gpu, 1000, 250, True, "reflect", padded_window_np("hann", 1000, 1000))
+    assert lib.mia_stft_moments(odd.handle, y.data_ptr(), 2, 3000, 1.0, out.data_ptr(), 1, 10, 0, 1,
+                                sums.data_ptr(), s) == _lib.MIA_ERR_UNSUPPORTED
 
 
 def test_contiguous_spectrogram_odd_tile_sizes_and_c_abi(gpu):
