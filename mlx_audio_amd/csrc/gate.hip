@@ -167,9 +167,11 @@ __global__ __launch_bounds__(256) void gate_mask_box_tiled_kernel(
     float* __restrict__ out) {
   __shared__ float vt[kGateKT + kGateMaxWin - 1][kGateFT];
   const unsigned row = blockIdx.z;
-  const int k0 = (int)blockIdx.y * kGateKT;
+  unsigned tile_f, tile_k;
+  if (!xcd_tile((F + kGateFT - 1) / kGateFT, (bins + kGateKT - 1) / kGateKT, tile_f, tile_k)) return;
+  const int k0 = (int)tile_k * kGateKT;
   const unsigned fx = threadIdx.x & (kGateFT - 1), ky = threadIdx.x / kGateFT;
-  const unsigned f = blockIdx.x * kGateFT + fx;
+  const unsigned f = tile_f * kGateFT + fx;
   const unsigned fc = f < F ? f : F - 1;
   const size_t plane = (size_t)row * bins * F;
   const int nrows = kGateKT + size - 1;
@@ -319,7 +321,9 @@ __global__ __launch_bounds__(256) void gate_apply_spectrum_tiled_kernel(
   constexpr int W = 32 + kGateMaxWin - 1;  // frames of the patch at most
   __shared__ float avg[32][W + 1];
   const long long row = blockIdx.z;
-  const long long f0 = (long long)blockIdx.x * 32, k0 = (long long)blockIdx.y * 32;
+  unsigned tile_f, tile_k;
+  if (!xcd_tile((unsigned)((F + 31) / 32), (unsigned)((bins + 31) / 32), tile_f, tile_k)) return;
+  const long long f0 = (long long)tile_f * 32, k0 = (long long)tile_k * 32;
   const long long base = row * bins * F;
   const int tid = threadIdx.y * 32 + threadIdx.x;
   const int nf = 32 + size_time - 1;
@@ -480,8 +484,12 @@ int mia_gate_mask_box(const float* mag, const float* thr, int64_t rows, int bins
     return MIA_OK;
   }
   if (size_freq <= kGateMaxWin) {
-    const dim3 tgrid((unsigned)((frames + kGateFT - 1) / kGateFT),
-                     (unsigned)((bins + kGateKT - 1) / kGateKT), (unsigned)rows);
+    // tiles of neighbouring bins read each other's halo rows: xcd_tile() order keeps them behind
+    // one L2
+    MIA_REQUIRE((unsigned long long)((frames + kGateFT - 1) / kGateFT) * ((bins + kGateKT - 1) / kGateKT) < (1ULL << 28),
+                "shape too large for one launch");
+    const dim3 tgrid(xcd_tile_grid((unsigned)((frames + kGateFT - 1) / kGateFT),
+                                   (unsigned)((bins + kGateKT - 1) / kGateKT)), 1, (unsigned)rows);
     hipLaunchKernelGGL(gate_mask_box_tiled_kernel, tgrid, dim3(256), 0, (hipStream_t)stream, mag, thr,
                        (unsigned)bins, (unsigned)frames, per_bin, (unsigned)rows_thr, gain, keep, p,
                        size_freq, out);
@@ -534,7 +542,11 @@ int mia_gate_apply_spectrum(const void* spec, const float* mask, int64_t rows, i
     const size_t off = (size_t)r0 * bins * frames;
     const dim3 grid((unsigned)((frames + 31) / 32), (unsigned)((bins + 31) / 32), (unsigned)nr);
     if (size_time <= kGateMaxWin) {
-      hipLaunchKernelGGL(gate_apply_spectrum_tiled_kernel, grid, dim3(32, 8), 0, (hipStream_t)stream,
+      // tiles of neighbouring bins share the cache lines their 256-byte runs of a spectrum row
+      // straddle: xcd_tile() order keeps them behind one L2
+      MIA_REQUIRE((unsigned long long)grid.x * grid.y < (1ULL << 28), "shape too large for one launch");
+      const dim3 tgrid(xcd_tile_grid(grid.x, grid.y), 1, grid.z);
+      hipLaunchKernelGGL(gate_apply_spectrum_tiled_kernel, tgrid, dim3(32, 8), 0, (hipStream_t)stream,
                          (const float2*)spec + off, mask + off, (long long)bins, (long long)frames,
                          keep, p, size_freq, size_time, (float2*)out + off);
     } else {

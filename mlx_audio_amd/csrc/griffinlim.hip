@@ -51,7 +51,9 @@ __global__ __launch_bounds__(256) void spectrum_part_kernel(const float2* __rest
                                                             float* __restrict__ out) {
   __shared__ float tile[32][33];
   const long long row = blockIdx.z;
-  const long long f0 = (long long)blockIdx.x * 32, k0 = (long long)blockIdx.y * 32;
+  unsigned tile_f, tile_k;
+  if (!xcd_tile((unsigned)((F + 31) / 32), (unsigned)((bins + 31) / 32), tile_f, tile_k)) return;
+  const long long f0 = (long long)tile_f * 32, k0 = (long long)tile_k * 32;
   const float2* __restrict__ src = z + row * F * bins;
   for (int j = threadIdx.y; j < 32; j += 8) {  // j: frame in the tile, x: bin
     const long long f = f0 + j, k = k0 + threadIdx.x;
@@ -91,7 +93,12 @@ int mia_spectrum_part(const void* z, int64_t rows, int64_t frames, int64_t bins,
     }
     return MIA_OK;
   }
-  const dim3 grid((unsigned)((frames + 31) / 32), (unsigned)((bins + 31) / 32), (unsigned)rows);
+  // tiles of neighbouring bins share the cache lines their 256-byte runs of a spectrum row
+  // straddle: xcd_tile() order keeps them behind one L2
+  MIA_REQUIRE((unsigned long long)((frames + 31) / 32) * ((bins + 31) / 32) < (1ULL << 28),
+              "spectrum too large for one launch");
+  const dim3 grid(xcd_tile_grid((unsigned)((frames + 31) / 32), (unsigned)((bins + 31) / 32)), 1,
+                  (unsigned)rows);
   hipLaunchKernelGGL(spectrum_part_kernel, grid, dim3(32, 8), 0, (hipStream_t)stream,
                      (const float2*)z, (long long)frames, (long long)bins, op, out);
   MIA_CHECK_HIP(hipGetLastError());

@@ -113,6 +113,21 @@ struct mia_plan {
 
 namespace mia {
 
+// Tile order for kernels whose neighbouring tiles (along ty) touch the same cache lines.
+// Workgroups are dealt to the eight XCDs in turn, each with its own L2, so a launch of
+// xcd_tile_grid(gx, gy) workgroups along x hands XCD k the k-th eighth of the gx * gy tiles, ty
+// running fastest: neighbours along ty sit behind one L2 and every XCD gets the same number of
+// tiles.  xcd_tile() returns false for the few workgroups past the last tile.
+static inline unsigned xcd_tile_grid(unsigned gx, unsigned gy) { return 8u * ((gx * gy + 7u) / 8u); }
+__device__ __forceinline__ bool xcd_tile(unsigned gx, unsigned gy, unsigned& tx, unsigned& ty) {
+  const unsigned total = gx * gy, per = (total + 7u) / 8u;
+  const unsigned t = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+  if (t >= total) return false;
+  tx = t / gy;
+  ty = t - tx * gy;
+  return true;
+}
+
 struct FwdParams {
   const float* y;
   long long B, T, F;

@@ -113,19 +113,20 @@ __global__ __launch_bounds__(256) void cac_normalize_kernel(const float2* __rest
                                                             float* __restrict__ stats) {
   __shared__ float2 tile[kCacTT][33];
   __shared__ float mean_inv[2];
-  if ((long long)blockIdx.x * kCacTT >= T) return;  // padding of the grid (see the launch)
+  unsigned tile_t, tile_f;
+  if (!xcd_tile((unsigned)((T + kCacTT - 1) / kCacTT), (unsigned)((F + 31) / 32), tile_t, tile_f)) return;
   const long long bc = blockIdx.z, b = bc / C, c = bc - b * C;
   if (threadIdx.x == 0 && threadIdx.y == 0) {
     float mean, inv;
     mean_std(sums + 2 * b, 2.0 * (double)C * (double)F * (double)T, eps, mean, inv);
     mean_inv[0] = mean;
     mean_inv[1] = inv;
-    if (c == 0 && blockIdx.x == 0 && blockIdx.y == 0) {
+    if (c == 0 && tile_t == 0 && tile_f == 0) {
       stats[2 * b] = mean;
       stats[2 * b + 1] = 1.0f / inv;
     }
   }
-  const long long f0 = (long long)blockIdx.y * 32, t0 = (long long)blockIdx.x * kCacTT;
+  const long long f0 = (long long)tile_f * 32, t0 = (long long)tile_t * kCacTT;
   const float2* __restrict__ src = spec + b * sb + c * sc;
 #pragma unroll
   for (int j = threadIdx.y; j < kCacTT; j += 8) {  // j: frame within the tile, x: bin
@@ -218,12 +219,12 @@ static int normalize_cac(const void* spec, int64_t batch, int channels, int64_t 
                        (long long)stride_b, (long long)stride_c, (long long)stride_f,
                        (long long)stride_t, (double*)sums);
   }
-  // grid.x is padded to a multiple of 8 (the extra workgroups leave at once): workgroups go to
-  // the eight XCDs in turn, and with that the tiles above and below one another - which share
-  // the cache lines their 256-byte runs of a spectrum row straddle - sit behind one L2
-  const unsigned tiles_t = (unsigned)((frames + kCacTT - 1) / kCacTT);
-  const dim3 grid((tiles_t + 7) / 8 * 8, (unsigned)((bins + 31) / 32), (unsigned)(batch * channels));
-  MIA_REQUIRE(grid.y <= 65535, "too many bins");
+  // tiles above and below one another share the cache lines their 256-byte runs of a spectrum
+  // row straddle: xcd_tile() order keeps them behind one L2 (FETCH_SIZE 1.46 x -> 1.00 x the
+  // spectrum)
+  const unsigned tiles_t = (unsigned)((frames + kCacTT - 1) / kCacTT), tiles_f = (unsigned)((bins + 31) / 32);
+  MIA_REQUIRE((unsigned long long)tiles_t * tiles_f < (1ULL << 28), "spectrogram too large for one launch");
+  const dim3 grid(xcd_tile_grid(tiles_t, tiles_f), 1, (unsigned)(batch * channels));
   hipLaunchKernelGGL(cac_normalize_kernel, grid, dim3(32, 8), 0, s, (const float2*)spec, channels,
                      (long long)bins, (long long)frames, (long long)stride_b, (long long)stride_c,
                      (long long)stride_f, (long long)stride_t, (const double*)sums, eps, out, stats);
