@@ -484,10 +484,7 @@ __global__ __launch_bounds__(WG, C::OCC) void fwd_kernel(FwdParams p) {
             mom_q += (double)z.x * (double)z.x + (double)z.y * (double)z.y;
           }
         } else {
-          float pw = 0.25f * (X.x * X.x + X.y * X.y);
-          if (p.power_mode == 1) pw = sqrtf(pw);
-          else if (p.power_mode == 2) pw = powf(sqrtf(pw), p.power);
-          prow[k] = pw;
+          prow[k] = 0.25f * (X.x * X.x + X.y * X.y);  // |X|^2; other exponents: the pass below
         }
       };
       static_for<0, RL>([&](auto rc) {
@@ -538,6 +535,21 @@ __global__ __launch_bounds__(WG, C::OCC) void fwd_kernel(FwdParams p) {
       atomicAdd(dst + 1, q);
     }
     __syncthreads();  // the next tile reuses the slots
+  }
+  if constexpr (MODE != 0) {
+    // Magnitudes or |X|^p instead of powers: one pass over the tile, decided once per tile.  In
+    // the split step above the choice was two scalar branches per bin pair, and seventeen
+    // inlined copies of powf stood between the hot path's instructions.
+    if (p.power_mode != 0) {
+      __syncthreads();
+      for (int i = tid; i < FT * PS; i += WG) {
+        const int fl = i / PS, k = i - fl * PS;
+        if (k <= M && f0 + fl < p.F) {
+          const float mag = sqrtf(P[i]);
+          P[i] = p.power_mode == 1 ? mag : powf(mag, p.power);
+        }
+      }
+    }
   }
   if constexpr (MODE == 2) {
     __syncthreads();
