@@ -282,7 +282,7 @@ __global__ __launch_bounds__(WG, C::OCC) void fwd_kernel(FwdParams p) {
     for (int r = 0; r < R0; ++r) xin[bb][r] = {0.0f, 0.0f};
   }
   auto prefetch = [&](long long idx_n, int it_n) {
-    const long long bn = idx_n / p.tiles;
+    const long long bn = (long long)((unsigned)idx_n / (unsigned)p.tiles);  // the launcher keeps the tile count below 2^32
     const long long fn = (idx_n - bn * p.tiles) * FT + it_n * G + g;
     const float* __restrict__ ybn = p.y + bn * p.T;
     const long long s0 = fn * p.hop - p.pad;
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(WG, C::OCC) void fwd_kernel(FwdParams p) {
 
   for (long long idx = first; idx < last; ++idx) {
   double mom_s = 0.0, mom_q = 0.0;  // MODE 5: this thread's share of the tile's moments
-  const long long b = idx / p.tiles;
+  const long long b = (long long)((unsigned)idx / (unsigned)p.tiles);
   const int tile = (int)(idx - b * p.tiles);
   const long long f0 = (long long)tile * FT;
   const float* __restrict__ yb = p.y + b * p.T;
@@ -797,6 +797,10 @@ static int launch_cfg(const FwdParams& p0, hipStream_t s) {
                 "LDS budget");
   const long long total = p.B * p.tiles;
   if (total <= 0) return MIA_OK;
+  if (total >= 0xffffffffLL) {  // the kernel divides tile indices in 32 bits
+    set_error("%lld tiles do not fit one launch (split the batch)", total);
+    return MIA_ERR_UNSUPPORTED;
+  }
   if (MODE == 3 &&
       (p.n_mels % 4 != 0 || sizeof(float) * (size_t)FT * p.n_mels > sizeof(float2) * G * C::LBUF)) {
     set_error("frame-major mel rows do not fit this plan's FFT buffers");
