@@ -177,6 +177,9 @@ __global__ __launch_bounds__(WG, C::OCC) void fwd_kernel(FwdParams p) {
   int g, t;
   bool active;
   C::map(tid, g, t, active);
+  // a group of whole waves: its index is the same in every lane, which the compiler cannot see
+  // (frame numbers, sample offsets and their range checks then run on the scalar unit)
+  if constexpr (C::T >= 64) g = __builtin_amdgcn_readfirstlane(g);
   float2* buf = bufs + (active ? g : 0) * C::LBUF;
   const float2* __restrict__ tw = p.tw;
   const float2* __restrict__ win2 = reinterpret_cast<const float2*>(p.win);
