@@ -15,7 +15,10 @@
 // butterfly, reads its R inputs L/R apart (consecutive threads read consecutive elements),
 // multiplies by twiddles it derives from one double-precision sincospi and a double recurrence,
 // and writes the R outputs of the autosort step; no LDS, no transposes, no twiddle tables.  An
-// inverse transform is the same machine applied to the conjugate spectrum.
+// inverse transform is the same machine applied to the conjugate spectrum.  Long rows of the
+// direct path whose length splits into two composite radices of at most 1024 take two
+// "super-passes" instead (stockham_super_kernel: the same pass to memory, its radix-R transform
+// done in LDS by up to three small butterflies), which halves the trips through memory.
 #include "fft_engine.h"
 #include "mia_internal.h"
 
