@@ -1,7 +1,11 @@
 // Spectral gating: the steps between the forward and the inverse STFT of a noise gate, on
-// magnitudes laid out (rows, bins, frames) with frames contiguous.  Every kernel is one thread
-// per output element (or per frame / per bin for the reductions) with consecutive lanes on
-// consecutive frames, so loads are coalesced row segments; windows are a handful of samples.
+// magnitudes laid out (rows, bins, frames) with frames contiguous.  The elementwise steps and
+// the reductions are one thread per output element (per frame / per bin) with consecutive lanes
+// on consecutive frames, so loads are coalesced row segments.  The two kernels a default call
+// spends its time in - mask + first frequency average, and the closing kernel that averages the
+// mask once more and scales the complex spectrum by it - work on LDS tiles (every mask value
+// computed once, loads independent of each other), handed out in xcd_tile() order; their
+// one-thread-per-output forms stay for windows wider than the tiles' halo.
 #include "mia_internal.h"
 
 namespace mia {

@@ -5,6 +5,8 @@
 // pair per workgroup); the spectrogram is read through its strides, as the strided view of the
 // STFT kernel's (rows, frames, bins) output that the front-end hands over, and written as
 // (batch, 2*channels, bins, frames) planes through an LDS tile so that both sides are coalesced.
+// The spectrogram's sums may also come from the STFT kernel itself (mia_stft_moments), which
+// saves the pass that adds them up here.
 #include "mia_internal.h"
 
 namespace mia {
