@@ -36,7 +36,12 @@ def _spec_and_sums(x, n_fft: int, hop_length: int, want_sums: bool):
     B, C, T = x.shape
     le = int(math.ceil(T / hop_length))
     pad = hop_length // 2 * 3
-    xp = torch.nn.functional.pad(x, (pad, pad + le * hop_length - T))
+    # the zero margins written by themselves: a pad() would first fill the whole buffer
+    right = pad + le * hop_length - T
+    xp = torch.empty((B, C, pad + T + right), dtype=x.dtype, device=x.device)
+    xp[..., :pad].zero_()
+    xp[..., pad + T:].zero_()
+    xp[..., pad:pad + T].copy_(x)
     scale = 1.0 / math.sqrt(n_fft)
     lib = _lib.lib()
     sums = None
