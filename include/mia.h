@@ -427,6 +427,13 @@ int mia_stft_moments(const mia_plan* plan, const float* y, int64_t B, int64_t T,
 int mia_normalize_cac_sums(const void* spec, int64_t batch, int channels, int64_t bins, int64_t frames,
                            int64_t stride_b, int64_t stride_c, int64_t stride_f, int64_t stride_t,
                            float eps, float* out, float* stats, const void* sums, void* stream);
+/* The way back (model.py:432-506, the complex-as-channels branch before the inverse STFT):
+ * planes: device float (rows, 2, bins, frames), real then imaginary part of each row's
+ * spectrogram, frames contiguous; out: device complex64 (rows, frames + 2 pad_frames,
+ * bins + pad_bins) in the order mia_istft reads fastest, the appended bins (HTDemucs: the one
+ * Nyquist bin it dropped) and the pad_frames frames on either side (HTDemucs: two) zero. */
+int mia_cac_to_spectrum(const float* planes, int64_t rows, int64_t bins, int64_t frames, int pad_bins,
+                        int pad_frames, void* out, void* stream);
 
 /* ---- Whisper encoder stem (models/whisper/layers/encoder.py:72-109) ----------------------
  * What AudioEncoder.__call__ does before its transformer blocks: x = mel^T (frames, n_mels);

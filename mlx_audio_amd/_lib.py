@@ -123,6 +123,7 @@ SIGNATURES = {
                                    c_void_p]),
     "mia_stft_moments": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_float, c_void_p, c_int, c_int,
                                  c_int64, c_int64, c_void_p, c_void_p]),
+    "mia_cac_to_spectrum": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p]),
     "mia_normalize_cac_sums": (c_int, [c_void_p, c_int64, c_int, c_int64, c_int64, c_int64, c_int64,
                                        c_int64, c_int64, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mia_normalize_cac": (c_int, [c_void_p, c_int64, c_int, c_int64, c_int64, c_int64, c_int64,

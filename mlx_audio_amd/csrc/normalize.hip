@@ -153,6 +153,40 @@ __global__ __launch_bounds__(256) void cac_normalize_kernel(const float2* __rest
   }
 }
 
+// The way back (what HTDemucs does before its inverse STFT): real and imaginary planes
+// planes[row, part, f, t] (t contiguous) become the complex spectrum out[row, t + pad_t, f] in the
+// (rows, frames, bins) order the inverse STFT kernel reads with coalesced rows, with pad_k zero
+// bins appended (the dropped Nyquist bin) and pad_t zero frames on either side, all written by
+// this one kernel.  Tiles of 32 bins x 64 frames of the OUTPUT through LDS, in xcd_tile() order;
+// 256 threads.
+__global__ __launch_bounds__(256) void cac_to_spectrum_kernel(const float* __restrict__ planes,
+                                                              long long F, long long T, int pad_k,
+                                                              int pad_t, float2* __restrict__ out) {
+  __shared__ float2 tile[kCacTT][33];
+  const long long Fo = F + pad_k, To = T + 2LL * pad_t;
+  unsigned tile_t, tile_f;
+  if (!xcd_tile((unsigned)((To + kCacTT - 1) / kCacTT), (unsigned)((Fo + 31) / 32), tile_t, tile_f)) return;
+  const long long row = blockIdx.z;
+  const long long f0 = (long long)tile_f * 32, t0 = (long long)tile_t * kCacTT;
+  const float* __restrict__ re = planes + row * 2 * F * T;
+  const float* __restrict__ im = re + F * T;
+  const int tx = threadIdx.y % 2 * 32 + threadIdx.x;  // frame within the tile: 64 per bin row
+#pragma unroll
+  for (int j = threadIdx.y / 2; j < 32; j += 4) {  // j: bin within the tile
+    const long long f = f0 + j, t = t0 + tx - pad_t;
+    float2 z = {0.0f, 0.0f};
+    if (f < F && t >= 0 && t < T) z = {re[f * T + t], im[f * T + t]};
+    tile[tx][j] = z;
+  }
+  __syncthreads();
+  float2* __restrict__ dst = out + row * To * Fo;
+#pragma unroll
+  for (int j = threadIdx.y; j < kCacTT; j += 8) {  // j: frame within the tile, x: bin
+    const long long f = f0 + threadIdx.x, t = t0 + j;
+    if (f < Fo && t < To) dst[t * Fo + f] = tile[j][threadIdx.x];
+  }
+}
+
 }  // namespace mia
 
 extern "C" {
@@ -246,6 +280,28 @@ int mia_normalize_cac_sums(const void* spec, int64_t batch, int channels, int64_
                            float eps, float* out, float* stats, const void* sums, void* stream) {
   return normalize_cac(spec, batch, channels, bins, frames, stride_b, stride_c, stride_f, stride_t, eps,
                        out, stats, const_cast<void*>(sums), 1, stream);
+}
+
+int mia_cac_to_spectrum(const float* planes, int64_t rows, int64_t bins, int64_t frames, int pad_bins,
+                        int pad_frames, void* out, void* stream) {
+  using namespace mia;
+  MIA_REQUIRE(rows >= 0 && bins >= 1 && frames >= 1 && pad_bins >= 0 && pad_frames >= 0,
+              "rows, bins, frames, pad_bins, pad_frames must be >= 0, 1, 1, 0, 0");
+  if (rows == 0) return MIA_OK;
+  MIA_REQUIRE(planes && out, "null pointer");
+  const unsigned tiles_t = (unsigned)((frames + 2LL * pad_frames + kCacTT - 1) / kCacTT);
+  const unsigned tiles_f = (unsigned)((bins + pad_bins + 31) / 32);
+  MIA_REQUIRE((unsigned long long)tiles_t * tiles_f < (1ULL << 28), "spectrogram too large for one launch");
+  const size_t in_row = 2 * (size_t)bins * (size_t)frames;
+  const size_t out_row = (size_t)(bins + pad_bins) * (size_t)(frames + 2LL * pad_frames);
+  for (int64_t r0 = 0; r0 < rows; r0 += 65535) {  // a launch takes 65535 rows
+    const int64_t nr = rows - r0 < 65535 ? rows - r0 : 65535;
+    hipLaunchKernelGGL(cac_to_spectrum_kernel, dim3(xcd_tile_grid(tiles_t, tiles_f), 1, (unsigned)nr),
+                       dim3(32, 8), 0, (hipStream_t)stream, planes + (size_t)r0 * in_row, (long long)bins,
+                       (long long)frames, pad_bins, pad_frames, (float2*)out + (size_t)r0 * out_row);
+  }
+  MIA_CHECK_HIP(hipGetLastError());
+  return MIA_OK;
 }
 
 }  // extern "C"

@@ -73,12 +73,14 @@ def htdemucs_ispec(m, length: int, n_fft: int = DEMUCS_N_FFT,
     m = as_device_f32(m, ndim_allowed=(5,))
     B, S, C2, F, Tf = m.shape
     C = C2 // 2
-    mr = m.reshape(B, S, C, 2, F, Tf)
-    # one zero Nyquist bin, two zero frames each side
-    z = torch.zeros((B * S * C, F + 1, Tf + 4), dtype=torch.complex64, device=m.device)
-    zv = torch.view_as_real(z)
-    zv[:, :F, 2:2 + Tf, 0] = mr[:, :, :, 0].reshape(B * S * C, F, Tf)
-    zv[:, :F, 2:2 + Tf, 1] = mr[:, :, :, 1].reshape(B * S * C, F, Tf)
+    # one zero Nyquist bin, two zero frames each side, real / imaginary planes interleaved, and
+    # the (rows, frames, bins) order the inverse kernel reads in whole rows: one launch
+    planes = m.contiguous()        # [B, S, C, 2, F, Tf] as it stands
+    z = torch.empty((B * S * C, Tf + 4, F + 1), dtype=torch.complex64, device=m.device)
+    with torch.cuda.device(m.device):
+        _lib.check(_lib.lib().mia_cac_to_spectrum(planes.data_ptr(), B * S * C, F, Tf, 1, 2,
+                                                  z.data_ptr(), stream_ptr(m.device)))
+    z = z.transpose(1, 2)          # (rows, F + 1, Tf + 4) view
     pad = hop_length // 2 * 3
     le = hop_length * int(math.ceil(length / hop_length)) + 2 * pad
     y = _istft_raw(z, n_fft, hop_length, n_fft, "hann", le + n_fft, scale=math.sqrt(n_fft))

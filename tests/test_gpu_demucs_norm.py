@@ -111,3 +111,43 @@ def test_contiguous_spectrogram_odd_tile_sizes_and_c_abi(gpu):
     torch.cuda.synchronize()
     np.testing.assert_allclose(out.cpu().numpy(), 0.0)               # a constant row: (1 - 1) / (0 + eps)
     np.testing.assert_allclose(st.cpu().numpy(), [1.0, 1e-5], rtol=1e-6)
+
+
+@pytest.mark.parametrize("rows,F,T,pk,pt", [(3, 45, 70, 1, 2), (1, 32, 64, 0, 0), (2, 1, 1, 1, 2), (2, 2048, 87, 1, 2),
+                                            (1, 33, 129, 3, 1)])
+def test_planes_to_spectrum(gpu, rows, F, T, pk, pt):
+    """mia_cac_to_spectrum: real / imaginary planes -> the (rows, frames, bins) complex spectrum with
+    zero bins appended and zero frames on both sides, bit for bit what assignment into a zeroed
+    array gives; and htdemucs_ispec through it equals the inverse STFT of that array."""
+    rng = np.random.default_rng(rows * 100 + F)
+    planes = rng.standard_normal((rows, 2, F, T)).astype(np.float32)
+    want = np.zeros((rows, T + 2 * pt, F + pk), dtype=np.complex64)
+    want[:, pt:pt + T, :F] = (planes[:, 0] + 1j * planes[:, 1]).transpose(0, 2, 1)
+    out = torch.full((rows, T + 2 * pt, F + pk), complex(7, 7), dtype=torch.complex64, device=gpu)
+    lib = _lib.lib()
+    s = torch.cuda.current_stream(gpu).cuda_stream
+    _lib.check(lib.mia_cac_to_spectrum(_dev(planes, gpu).data_ptr(), rows, F, T, pk, pt, out.data_ptr(), s))
+    np.testing.assert_array_equal(out.cpu().numpy(), want)
+    assert lib.mia_cac_to_spectrum(0, rows, F, T, pk, pt, out.data_ptr(), s) == _lib.MIA_ERR_INVALID
+    assert lib.mia_cac_to_spectrum(out.data_ptr(), rows, 0, T, pk, pt, out.data_ptr(), s) == _lib.MIA_ERR_INVALID
+    assert lib.mia_cac_to_spectrum(0, 0, F, T, pk, pt, 0, s) == _lib.MIA_OK
+
+
+def test_ispec_equals_the_inverse_stft_of_the_assembled_spectrum(gpu):
+    from mlx_audio_amd.frontends import htdemucs_ispec
+    from mlx_audio_amd.primitives import istft
+
+    rng = np.random.default_rng(9)
+    B, S, C, F, Tf, length = 2, 2, 2, 2048, 12, 9000
+    m = rng.standard_normal((B, S, 2 * C, F, Tf)).astype(np.float32)
+    got = htdemucs_ispec(_dev(m, gpu), length)
+    mr = m.reshape(B * S * C, 2, F, Tf)
+    z = np.zeros((B * S * C, F + 1, Tf + 4), dtype=np.complex64)
+    z[:, :F, 2:2 + Tf] = mr[:, 0] + 1j * mr[:, 1]
+    pad = 1024 // 2 * 3
+    le = 1024 * int(np.ceil(length / 1024)) + 2 * pad
+    y = istft(_dev(z, gpu), hop_length=1024, n_fft=4096, length=le) * np.float32(np.sqrt(4096))
+    want = y.reshape(B, S, C, -1)[:, :, :, pad:pad + length]
+    assert got.shape == (B, S, C, length)
+    np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=0, atol=2e-5 * float(want.abs().max()))
+
