@@ -344,6 +344,13 @@ int mia_onset_flux(const float* S, int64_t rows, int bands, int64_t frames, int 
 int mia_envelope_filter(const float* src, int64_t rows, int64_t n, int64_t src_stride, int size,
                         int mode, float* dst, int64_t dst_stride, void* stream);
 
+/* in: complex64 (rows, bins, frames) with frames contiguous (the layout the reference's stft
+ * returns and its istft takes, stft.py:222, 225); out: the same values as (rows, frames, bins),
+ * the layout mia_stft writes and mia_istft reads fastest (stride_bin = 1).  For callers who hold
+ * a spectrum in the first layout: transposing it first and handing mia_istft whole rows is several
+ * times faster than its strided path. */
+int mia_transpose_spectrum(const void* in, int64_t rows, int64_t bins, int64_t frames, void* out,
+                           void* stream);
 /* ---- Griffin-Lim (primitives/griffinlim.py) -----------------------------------------
  * out[i] = mag[i] * exp(i angle[i]) (griffinlim.py:121, 247): n complex64 values. */
 int mia_polar(const float* mag, const float* angle, int64_t n, void* out, void* stream);

@@ -129,6 +129,7 @@ SIGNATURES = {
     "mia_normalize_cac": (c_int, [c_void_p, c_int64, c_int, c_int64, c_int64, c_int64, c_int64,
                                   c_int64, c_int64, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mia_spectrum_part": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_void_p]),
+    "mia_transpose_spectrum": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p]),
     "mia_polar": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "mia_griffinlim_update": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float,
                                       c_void_p]),

@@ -91,8 +91,18 @@ def _istft_raw(spec: torch.Tensor, n_fft, hop_length, win_length, window, padded
     if bins != n_fft // 2 + 1:
         raise ValueError(f"stft_matrix has {bins} bins but n_fft={n_fft} needs {n_fft // 2 + 1}")
     lib = _lib.lib()
-    out = torch.empty((B, padded_length), dtype=torch.float32, device=spec.device)
     ws_bytes = lib.mia_istft_workspace_bytes(plan.handle, B, F)
+    if (ws_bytes == 0 and F > 1 and bins > 1 and spec.stride(2) == 1 and spec.stride(1) == F
+            and spec.stride(0) == bins * F):
+        # frames contiguous (the reference's layout) and a plan whose inverse is the fused kernel
+        # (no workspace: the overlap stays in LDS), which reads whole rows of bins and is several
+        # times slower through strides: one transposing pass first
+        rows_first = torch.empty((B, F, bins), dtype=torch.complex64, device=spec.device)
+        with torch.cuda.device(spec.device):
+            _lib.check(lib.mia_transpose_spectrum(spec.data_ptr(), B, bins, F, rows_first.data_ptr(),
+                                                  stream_ptr(spec.device)))
+        spec = rows_first.transpose(1, 2)
+    out = torch.empty((B, padded_length), dtype=torch.float32, device=spec.device)
     ws = torch.empty((max(ws_bytes, 1),), dtype=torch.uint8, device=spec.device)
     sb, sk, sf = spec.stride()
     with torch.cuda.device(spec.device):

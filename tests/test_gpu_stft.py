@@ -338,3 +338,31 @@ def test_any_length_plans_reject_the_entry_points_without_workspace(gpu):
     assert lib.mia_stft_workspace_bytes(plan.handle, 1, 1000) > 0
     rc = lib.mia_stft(plan.handle, y.data_ptr(), 1, 1000, 1.0, out.data_ptr(), None)
     assert rc == _lib.MIA_ERR_INVALID and b"mia_stft_ws" in lib.mia_last_error()
+
+
+@pytest.mark.parametrize("n_fft,hop", [(1024, 256), (2048, 512), (4096, 1024), (512, 128), (400, 160)])
+def test_istft_of_a_frames_contiguous_spectrum(gpu, n_fft, hop):
+    """A contiguous (batch, bins, frames) array - the reference's layout - gives bit for bit what
+    the (batch, frames, bins) view stft() returns gives (the fused sizes transpose it first:
+    mia_transpose_spectrum), odd frame counts and a single row included."""
+    from mlx_audio_amd import _lib
+    from mlx_audio_amd.primitives import istft, stft
+
+    g = torch.Generator(device=gpu)
+    g.manual_seed(n_fft)
+    for rows, T in ((3, 9 * n_fft + 37), (1, 2 * n_fft)):
+        y = torch.randn((rows, T), generator=g, device=gpu)
+        S = stft(y, n_fft=n_fft, hop_length=hop)
+        Sc = S.contiguous()
+        assert Sc.stride(2) == 1
+        a = istft(S, hop_length=hop, length=T)
+        b = istft(Sc, hop_length=hop, length=T)
+        assert torch.equal(a, b)
+        assert torch.equal(istft(Sc[0], hop_length=hop, length=T), a[0])
+    lib = _lib.lib()
+    s = torch.cuda.current_stream(gpu).cuda_stream
+    out = torch.empty((rows, S.shape[2], S.shape[1]), dtype=torch.complex64, device=gpu)
+    _lib.check(lib.mia_transpose_spectrum(Sc.data_ptr(), rows, S.shape[1], S.shape[2], out.data_ptr(), s))
+    assert torch.equal(torch.view_as_real(out), torch.view_as_real(S.transpose(1, 2).contiguous()))
+    assert lib.mia_transpose_spectrum(Sc.data_ptr(), rows, S.shape[1], S.shape[2], Sc.data_ptr(), s) == _lib.MIA_ERR_INVALID
+
