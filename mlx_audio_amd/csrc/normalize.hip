@@ -153,6 +153,70 @@ __global__ __launch_bounds__(256) void cac_normalize_kernel(const float2* __rest
   }
 }
 
+// The same two steps for a spectrogram held with frames fastest ([batch, channels, bins, frames]
+// as the reference holds it, or a slice of such an array: stride_t == 1, any stride_f): input and
+// output then share their element order, so a workgroup walks rows of `frames` elements straight
+// through (the tiled kernel above would read such an array through a stride of stride_f elements).
+__global__ __launch_bounds__(256) void cac_moments_rows_kernel(const float2* __restrict__ spec, int C,
+                                                               long long F, long long T, long long sb,
+                                                               long long sc, long long sf,
+                                                               double* __restrict__ sums) {
+  const long long bc = blockIdx.y, b = bc / C, c = bc - b * C;
+  const float2* __restrict__ plane = spec + b * sb + c * sc;
+  double s2[2] = {0.0, 0.0}, q2[2] = {0.0, 0.0};
+  for (long long f = blockIdx.x; f < F; f += gridDim.x) {
+    const float2* __restrict__ line = plane + f * sf;
+    long long t = threadIdx.x;
+    for (; t + 256 < T; t += 512) {  // two loads in flight per thread
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const float2 z = line[t + 256 * k];
+        s2[k] += (double)z.x + (double)z.y;
+        q2[k] += (double)z.x * (double)z.x + (double)z.y * (double)z.y;
+      }
+    }
+    if (t < T) {
+      const float2 z = line[t];
+      s2[0] += (double)z.x + (double)z.y;
+      q2[0] += (double)z.x * (double)z.x + (double)z.y * (double)z.y;
+    }
+  }
+  block_accumulate(s2[0] + s2[1], q2[0] + q2[1], sums + 2 * b);
+}
+
+__global__ __launch_bounds__(256) void cac_normalize_rows_kernel(const float2* __restrict__ spec, int C,
+                                                                 long long F, long long T, long long sb,
+                                                                 long long sc, long long sf,
+                                                                 const double* __restrict__ sums,
+                                                                 float eps, float* __restrict__ out,
+                                                                 float* __restrict__ stats) {
+  __shared__ float mean_inv[2];
+  const long long bc = blockIdx.y, b = bc / C, c = bc - b * C;
+  if (threadIdx.x == 0) {
+    float mean, inv;
+    mean_std(sums + 2 * b, 2.0 * (double)C * (double)F * (double)T, eps, mean, inv);
+    mean_inv[0] = mean;
+    mean_inv[1] = inv;
+    if (c == 0 && blockIdx.x == 0) {
+      stats[2 * b] = mean;
+      stats[2 * b + 1] = 1.0f / inv;
+    }
+  }
+  __syncthreads();
+  const float mean = mean_inv[0], inv = mean_inv[1];
+  const float2* __restrict__ plane = spec + b * sb + c * sc;
+  float* __restrict__ re = out + ((b * 2 * C + 2 * c) * F) * T;
+  float* __restrict__ im = re + F * T;
+  for (long long f = blockIdx.x; f < F; f += gridDim.x) {
+    const float2* __restrict__ line = plane + f * sf;
+    for (long long t = threadIdx.x; t < T; t += 256) {
+      const float2 z = line[t];
+      re[f * T + t] = (z.x - mean) * inv;
+      im[f * T + t] = (z.y - mean) * inv;
+    }
+  }
+}
+
 // The way back (what HTDemucs does before its inverse STFT): real and imaginary planes
 // planes[row, part, f, t] (t contiguous) become the complex spectrum out[row, t + pad_t, f] in the
 // (rows, frames, bins) order the inverse STFT kernel reads with coalesced rows, with pad_k zero
@@ -244,6 +308,23 @@ static int normalize_cac(const void* spec, int64_t batch, int channels, int64_t 
     return MIA_OK;
   }
   hipStream_t s = (hipStream_t)stream;
+  if (stride_t == 1) {  // frames fastest: rows walked straight through, no transposition
+    long long chunks = bins;
+    const long long cap = 8192 / (batch * channels) > 1 ? 8192 / (batch * channels) : 1;
+    if (chunks > cap) chunks = cap;
+    const dim3 rgrid((unsigned)chunks, (unsigned)(batch * channels));
+    if (!have_sums) {
+      MIA_CHECK_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 2 * (size_t)batch, s));
+      hipLaunchKernelGGL(cac_moments_rows_kernel, rgrid, dim3(256), 0, s, (const float2*)spec, channels,
+                         (long long)bins, (long long)frames, (long long)stride_b, (long long)stride_c,
+                         (long long)stride_f, (double*)sums);
+    }
+    hipLaunchKernelGGL(cac_normalize_rows_kernel, rgrid, dim3(256), 0, s, (const float2*)spec, channels,
+                       (long long)bins, (long long)frames, (long long)stride_b, (long long)stride_c,
+                       (long long)stride_f, (const double*)sums, eps, out, stats);
+    MIA_CHECK_HIP(hipGetLastError());
+    return MIA_OK;
+  }
   if (!have_sums) {
     MIA_CHECK_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 2 * (size_t)batch, s));
     long long chunks = frames;
