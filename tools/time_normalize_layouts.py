@@ -1,5 +1,8 @@
+# htdemucs_normalize on the two layouts of the spectrogram: the strided view htdemucs_spec returns
+# and a contiguous [B, C, F, T] array (frames fastest): python tools/time_normalize_layouts.py
 import sys, time
-sys.path.insert(0, "/root/repo")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from mlx_audio_amd.frontends import htdemucs_normalize, htdemucs_spec
 def timed(fn, n=10):
