@@ -405,6 +405,20 @@ int mia_gate_apply(const float* mag, const float* mask, const float* phase, int6
 int mia_gate_apply_spectrum(const void* spec, const float* mask, int64_t rows, int64_t bins,
                             int64_t frames, int keep, float p, int size_freq, int size_time,
                             void* out, void* stream);
+/* The stationary gate without a magnitude plane: the same three steps taken from the complex
+ * spectrum itself, spec complex64 (rows, frames, bins) as mia_stft writes it, |z| = hypotf(re, im)
+ * on the fly.  mia_noise_threshold_spec and mia_gate_mask_box_spec (per-bin thresholds, windows
+ * of up to 33 bins: MIA_ERR_UNSUPPORTED beyond) are bit-identical to mia_noise_threshold and
+ * mia_gate_mask_box on mia_magnitude's plane; mia_frame_energy_spec adds the bins in another
+ * order (equal to float32 rounding).  Outputs as those calls': energy (rows, frames), thr (rows,
+ * bins), out (rows, bins, frames). */
+int mia_frame_energy_spec(const void* spec, int64_t rows, int bins, int64_t frames, float* energy,
+                          void* stream);
+int mia_noise_threshold_spec(const void* spec, int64_t rows, int bins, int64_t frames, const int* frame_idx,
+                             int n_selected, float n_std, float* thr, void* stream);
+int mia_gate_mask_box_spec(const void* spec, const float* thr, int64_t rows, int bins, int64_t frames,
+                           int64_t rows_thr, float gain, int keep, float p, int size_freq, float* out,
+                           void* stream);
 
 /* ---- HTDemucs input normalisation (models/demucs/model.py:206-233) ---------------------
  * mia_normalize_rows: per row of n floats, mean and population standard deviation, then

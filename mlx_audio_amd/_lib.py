@@ -116,6 +116,11 @@ SIGNATURES = {
                                c_float, c_int, c_void_p, c_void_p]),
     "mia_gate_apply_spectrum": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int,
                                         c_float, c_int, c_int, c_void_p, c_void_p]),
+    "mia_frame_energy_spec": (c_int, [c_void_p, c_int64, c_int, c_int64, c_void_p, c_void_p]),
+    "mia_noise_threshold_spec": (c_int, [c_void_p, c_int64, c_int, c_int64, c_void_p, c_int, c_float,
+                                         c_void_p, c_void_p]),
+    "mia_gate_mask_box_spec": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int64, c_int64, c_float,
+                                       c_int, c_float, c_int, c_void_p, c_void_p]),
     "mia_gate_mask_box": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int64, c_int, c_int64,
                                   c_float, c_int, c_float, c_int, c_void_p, c_void_p]),
     "mia_mask_op": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p, c_void_p]),

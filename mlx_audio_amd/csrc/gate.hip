@@ -17,6 +17,13 @@ constexpr float kGateEps = 1e-8f;  // the reference's DIVISION_EPSILON
 __device__ __forceinline__ double window_inv(int size) { return 1.0 / (double)size; }
 __device__ __forceinline__ float window_mean(double sum, double inv) { return (float)(sum * inv); }
 
+// The soft mask value clip((m - t * gain) / (m + eps), 0, 1), with the product and the difference
+// as one fused multiply-add spelled out: left to the compiler, the contraction differs between
+// kernels and the fused forms would not be bit-identical to the separate launches.
+__device__ __forceinline__ float gate_mask_value(float m, float t, float gain) {
+  return fminf(fmaxf(__builtin_fmaf(-t, gain, m) / (m + kGateEps), 0.0f), 1.0f);
+}
+
 // energy[row, f] = mean over bins of mag^2.  A block takes 32 frames; eight groups of threads
 // each sum every eighth bin (one thread per frame could keep only a few hundred waves in
 // flight, each behind a chain of `bins` loads), and the eight partial sums are added in a fixed
@@ -127,8 +134,7 @@ __global__ __launch_bounds__(256) void gate_mask_kernel(const float* __restrict_
     t = thr[g];
   }
   const float m = mag[g];
-  const float v = (m - t * gain) / (m + kGateEps);
-  mask[g] = fminf(fmaxf(v, 0.0f), 1.0f);
+  mask[g] = gate_mask_value(m, t, gain);
 }
 
 // The soft mask, optionally the keep step, and a moving average over `size` bins in one pass:
@@ -153,7 +159,7 @@ __global__ __launch_bounds__(256) void gate_mask_box_kernel(const float* __restr
     const size_t i = plane + (size_t)q * F + f;
     const float t = per_bin ? thr[(rows_thr == 1 ? 0 : (size_t)row * bins) + q] : thr[i];
     const float m = mag[i];
-    float v = fminf(fmaxf((m - t * gain) / (m + kGateEps), 0.0f), 1.0f);
+    float v = gate_mask_value(m, t, gain);
     if (keep) v = 1.0f - p * (1.0f - v);
     sum += (double)v;
   }
@@ -186,7 +192,7 @@ __global__ __launch_bounds__(256) void gate_mask_box_tiled_kernel(
     const size_t i = plane + (size_t)q * F + fc;
     const float t = per_bin ? thr[(rows_thr == 1 ? 0 : (size_t)row * bins) + q] : thr[i];
     const float m = mag[i];
-    float v = fminf(fmaxf((m - t * gain) / (m + kGateEps), 0.0f), 1.0f);
+    float v = gate_mask_value(m, t, gain);
     if (keep) v = 1.0f - p * (1.0f - v);
     vt[kk][fx] = v;
   }
@@ -379,6 +385,109 @@ __global__ __launch_bounds__(256) void gate_apply_spectrum_tiled_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------
+// The stationary gate straight from the complex spectrum (rows, frames, bins) the STFT kernel
+// wrote: frame energy, noise threshold and mask + first frequency average take |z| = hypotf(re,
+// im) as they go - the value the magnitude plane would have held - so that plane (one write and
+// three reads of a spectrum-sized float array, plus its launch) is never made.
+// ---------------------------------------------------------------------------
+// energy[row, f] = mean over bins of |z|^2: one wave per frame (its bins are contiguous), lanes
+// stride the bins, a fixed shuffle tree adds the lanes.
+__global__ __launch_bounds__(256) void frame_energy_spec_kernel(const float2* __restrict__ spec,
+                                                                long long rows, int bins, long long F,
+                                                                float* __restrict__ energy) {
+  const long long frame = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);  // over rows * F
+  if (frame >= rows * F) return;  // whole waves leave together
+  const int lane = threadIdx.x & 63;
+  const float2* __restrict__ line = spec + frame * bins;
+  float acc = 0.0f;
+#pragma unroll 4
+  for (int k = lane; k < bins; k += 64) {
+    const float2 z = line[k];
+    const float m = hypotf(z.x, z.y);
+    acc += m * m;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+  if (lane == 0) energy[frame] = acc / (float)bins;
+}
+
+// thr[row, bin] = mean + n_std * std (population) of |spec[row, idx[row, q], bin]|, q < n_sel (idx ==
+// nullptr: every frame), summed in the order noise_threshold_kernel sums them: bit-identical to
+// it on the magnitude plane.  One thread per bin, so a frame's values are read as one run.
+__global__ __launch_bounds__(256) void noise_threshold_spec_kernel(const float2* __restrict__ spec,
+                                                                   long long rows, int bins, long long F,
+                                                                   const int* __restrict__ idx, int n_sel,
+                                                                   float n_std, float* __restrict__ thr) {
+  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= rows * bins) return;
+  const long long row = g / bins, k = g - row * bins;
+  const float2* __restrict__ col = spec + row * F * bins + k;
+  const int* __restrict__ sel = idx ? idx + row * n_sel : nullptr;
+  const int n = sel ? n_sel : (int)F;
+  float sum = 0.0f;
+  for (int q = 0; q < n; ++q) {
+    const float2 z = col[(long long)(sel ? sel[q] : q) * bins];
+    sum += hypotf(z.x, z.y);
+  }
+  const float mean = sum / (float)n;
+  float ss = 0.0f;
+  for (int q = 0; q < n; ++q) {
+    const float2 z = col[(long long)(sel ? sel[q] : q) * bins];
+    const float d = hypotf(z.x, z.y) - mean;
+    ss += d * d;
+  }
+  thr[g] = mean + n_std * sqrtf(ss / (float)n);
+}
+
+// gate_mask_box_tiled_kernel with the magnitudes taken from the spectrum: the tile's bins (and
+// the window's halo) of 64 frames are read frame by frame (runs of up to 64 complex values),
+// turned into mask values and laid down in LDS with frames along the rows; the window sums and
+// the (rows, bins, frames) store are those of the magnitude form, bit for bit.  thr is per bin.
+__global__ __launch_bounds__(256) void gate_mask_box_spec_kernel(
+    const float2* __restrict__ spec, const float* __restrict__ thr, unsigned bins, unsigned F,
+    unsigned rows_thr, float gain, int keep, float p, int size, float* __restrict__ out) {
+  __shared__ float vt[kGateKT + kGateMaxWin - 1][kGateFT + 1];
+  const unsigned row = blockIdx.z;
+  unsigned tile_f, tile_k;
+  if (!xcd_tile((F + kGateFT - 1) / kGateFT, (bins + kGateKT - 1) / kGateKT, tile_f, tile_k)) return;
+  const int k0 = (int)tile_k * kGateKT;
+  const unsigned f0 = tile_f * kGateFT;
+  const int nrows = kGateKT + size - 1;
+  const double inv = window_inv(size);
+  const float2* __restrict__ plane = spec + (size_t)row * F * bins;
+  const float* __restrict__ thr_row = thr + (rows_thr == 1 ? 0 : (size_t)row * bins);
+  {
+    const int kk = threadIdx.x & 63;  // bin of the patch (nrows <= 64)
+    if (kk < nrows) {
+      const int j = k0 - size / 2 + kk;
+      const unsigned q = j < 0 ? 0u : (j >= (int)bins ? bins - 1 : (unsigned)j);
+      const float t = thr_row[q];
+#pragma unroll 4
+      for (unsigned fl = threadIdx.x >> 6; fl < (unsigned)kGateFT; fl += 4) {
+        const unsigned f = f0 + fl, fc = f < F ? f : F - 1;
+        const float2 z = plane[(size_t)fc * bins + q];
+        const float m = hypotf(z.x, z.y);
+        float v = gate_mask_value(m, t, gain);
+        if (keep) v = 1.0f - p * (1.0f - v);
+        vt[kk][fl] = v;
+      }
+    }
+  }
+  __syncthreads();
+  const unsigned fx = threadIdx.x & (kGateFT - 1), ky = threadIdx.x / kGateFT;
+  const unsigned f = f0 + fx;
+  if (f >= F) return;
+  const size_t oplane = (size_t)row * bins * F;
+  for (int kl = (int)ky; kl < kGateKT; kl += 256 / kGateFT) {
+    const unsigned k = (unsigned)(k0 + kl);
+    if (k >= bins) break;
+    double sum = 0.0;
+    for (int j = 0; j < size; ++j) sum += (double)vt[kl + j][fx];
+    out[oplane + (size_t)k * F + f] = size == 1 ? (float)sum : window_mean(sum, inv);
+  }
+}
+
 static inline unsigned gate_blocks(long long n) { return (unsigned)((n + 255) / 256); }
 
 }  // namespace mia
@@ -562,6 +671,67 @@ int mia_gate_apply_spectrum(const void* spec, const float* mask, int64_t rows, i
     }
     MIA_CHECK_HIP(hipGetLastError());
   }
+  return MIA_OK;
+}
+
+int mia_frame_energy_spec(const void* spec, int64_t rows, int bins, int64_t frames, float* energy,
+                          void* stream) {
+  using namespace mia;
+  MIA_REQUIRE(rows >= 0 && bins >= 1 && frames >= 0, "rows, bins, frames must be >= 0, 1, 0");
+  if (rows == 0 || frames == 0) return MIA_OK;
+  MIA_REQUIRE(spec && energy, "null pointer");
+  MIA_REQUIRE((rows * frames + 3) / 4 <= 0x7fffffffLL, "too many frames for one launch");
+  hipLaunchKernelGGL(frame_energy_spec_kernel, dim3((unsigned)((rows * frames + 3) / 4)), dim3(256), 0,
+                     (hipStream_t)stream, (const float2*)spec, (long long)rows, bins, (long long)frames,
+                     energy);
+  MIA_CHECK_HIP(hipGetLastError());
+  return MIA_OK;
+}
+
+int mia_noise_threshold_spec(const void* spec, int64_t rows, int bins, int64_t frames, const int* frame_idx,
+                             int n_selected, float n_std, float* thr, void* stream) {
+  using namespace mia;
+  MIA_REQUIRE(rows >= 0 && bins >= 1 && frames >= 1, "rows, bins, frames must be >= 0, 1, 1");
+  MIA_REQUIRE(frame_idx == nullptr || n_selected >= 1, "n_selected must be >= 1");
+  MIA_REQUIRE(frames <= 0x7fffffffLL, "too many frames");
+  if (rows == 0) return MIA_OK;
+  MIA_REQUIRE(spec && thr, "null pointer");
+  hipLaunchKernelGGL(noise_threshold_spec_kernel, dim3(gate_blocks(rows * bins)), dim3(256), 0,
+                     (hipStream_t)stream, (const float2*)spec, (long long)rows, bins, (long long)frames,
+                     frame_idx, n_selected, n_std, thr);
+  MIA_CHECK_HIP(hipGetLastError());
+  return MIA_OK;
+}
+
+int mia_gate_mask_box_spec(const void* spec, const float* thr, int64_t rows, int bins, int64_t frames,
+                           int64_t rows_thr, float gain, int keep, float p, int size_freq, float* out,
+                           void* stream) {
+  using namespace mia;
+  MIA_REQUIRE(rows >= 0 && bins >= 1 && frames >= 0 && size_freq >= 1,
+              "rows, bins, frames, size_freq must be >= 0, 1, 0, 1");
+  MIA_REQUIRE(rows_thr == rows || rows_thr == 1,
+              "the per-bin threshold must have one row per signal row, or a single row");
+  if (size_freq > kGateMaxWin) {
+    set_error("size_freq=%d: the spectrum form takes windows of up to %d bins (use mia_gate_mask_box "
+              "on the magnitudes)", size_freq, kGateMaxWin);
+    return MIA_ERR_UNSUPPORTED;
+  }
+  if (rows == 0 || frames == 0) return MIA_OK;
+  MIA_REQUIRE(spec && thr && out, "null pointer");
+  MIA_REQUIRE(frames <= 0x7fffffffLL, "shape too large for one launch");
+  const unsigned tiles_f = (unsigned)((frames + kGateFT - 1) / kGateFT);
+  const unsigned tiles_k = (unsigned)((bins + kGateKT - 1) / kGateKT);
+  MIA_REQUIRE((unsigned long long)tiles_f * tiles_k < (1ULL << 28), "shape too large for one launch");
+  const size_t per_row = (size_t)bins * (size_t)frames;
+  for (int64_t r0 = 0; r0 < rows; r0 += 65535) {  // a launch takes 65535 rows
+    const int64_t nr = rows - r0 < 65535 ? rows - r0 : 65535;
+    hipLaunchKernelGGL(gate_mask_box_spec_kernel, dim3(xcd_tile_grid(tiles_f, tiles_k), 1, (unsigned)nr),
+                       dim3(256), 0, (hipStream_t)stream, (const float2*)spec + (size_t)r0 * per_row,
+                       rows_thr == 1 ? thr : thr + (size_t)r0 * bins, (unsigned)bins, (unsigned)frames,
+                       (unsigned)(rows_thr == 1 ? 1 : nr), gain, keep, p, size_freq,
+                       out + (size_t)r0 * per_row);
+  }
+  MIA_CHECK_HIP(hipGetLastError());
   return MIA_OK;
 }
 

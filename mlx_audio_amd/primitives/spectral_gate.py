@@ -29,6 +29,9 @@ def _validate(n_fft, hop_length, prop_decrease) -> None:
         raise ValueError(f"prop_decrease must be <= 1.0, got {prop_decrease}")
 
 
+_SPEC_MASK_MAX_WINDOW = 33   # bins the spectrum form of the mask kernel averages at most
+
+
 class _Ops:
     """Thin launcher around the gating entry points for one device."""
 
@@ -122,16 +125,43 @@ class _Ops:
                   float(prop_decrease), int(size_freq), out.data_ptr())
         return out
 
+    # -- the same three steps straight from the complex (rows, frames, bins) spectrum ----------
+    def frame_energy_spec(self, spec_rows):
+        rows, frames, bins = spec_rows.shape
+        out = self.new((rows, frames))
+        self._run("mia_frame_energy_spec", spec_rows.data_ptr(), rows, bins, frames, out.data_ptr())
+        return out
+
+    def noise_threshold_spec(self, spec_rows, idx, n_std):
+        rows, frames, bins = spec_rows.shape
+        out = self.new((rows, bins))
+        self._run("mia_noise_threshold_spec", spec_rows.data_ptr(), rows, bins, frames,
+                  0 if idx is None else idx.data_ptr(), 0 if idx is None else idx.shape[1],
+                  float(n_std), out.data_ptr())
+        return out
+
+    def mask_box_spec(self, spec_rows, thr, gain, keep, prop_decrease, size_freq):
+        """mask_box() with the magnitudes taken from the spectrum; thr (rows or 1, bins)."""
+        rows, frames, bins = spec_rows.shape
+        out = self.new((rows, bins, frames))
+        self._run("mia_gate_mask_box_spec", spec_rows.data_ptr(), thr.data_ptr(), rows, bins, frames,
+                  thr.shape[0], float(gain), int(bool(keep)), float(prop_decrease), int(size_freq),
+                  out.data_ptr())
+        return out
+
     def gate(self, mag, spec, thr, gain, steps, keep_first, prop_decrease):
         """The mask pipeline with its first frequency average folded into the mask kernel and
         its last time average folded into the closing kernel, which scales the spectrum `spec`
-        the magnitudes came from.  steps: [(axis, size), ...] with axis "f" or "t", sizes > 1;
+        the magnitudes came from (mag None: the mask kernel takes them from `spec` itself).  steps: [(axis, size), ...] with axis "f" or "t", sizes > 1;
         keep_first: the keep step comes before the averages (the adaptive variant) instead of
         after them."""
         steps = list(steps)
         first = steps.pop(0)[1] if steps and steps[0][0] == "f" else 1
         last = steps.pop()[1] if steps and steps[-1][0] == "t" else 1
-        mask = self.mask_box(mag, thr, gain, keep_first, prop_decrease, first)
+        if mag is None:   # no magnitude plane was made: the mask comes from the spectrum itself
+            mask = self.mask_box_spec(spec.transpose(1, 2), thr, gain, keep_first, prop_decrease, first)
+        else:
+            mask = self.mask_box(mag, thr, gain, keep_first, prop_decrease, first)
         # a frequency average right before the closing kernel's time average rides along in it
         last_freq = steps.pop()[1] if steps and steps[-1][0] == "f" else 1
         for axis, size in steps:
@@ -163,24 +193,9 @@ def spectral_gate(audio, noise_profile=None, *, sr: int = 22050, n_fft: int = 20
         x = x[None]
     n_samples = x.shape[-1]
     kw = dict(n_fft=n_fft, hop_length=hop_length, win_length=win_length, window=window, center=True)
-    C = stft(x, **kw)   # magnitude / phase transpose it to (rows, bins, frames) as they go
-    mag = magnitude(C)
-    ops = _Ops(mag.device)
-    rows, bins, frames = mag.shape
-
-    if noise_profile is not None:
-        noise = as_device_f32(noise_profile)
-        noise_mag = magnitude(stft(noise if noise.dim() > 1 else noise[None], **kw))
-        if noise_mag.shape[0] not in (1, rows):
-            raise ValueError(f"noise_profile has {noise_mag.shape[0]} rows, the audio {rows}")
-        thr = ops.noise_threshold(noise_mag, None, n_std_thresh)
-    elif stationary:
-        n_quiet = max(1, int(0.1 * frames))
-        order = torch.sort(ops.frame_energy(mag), dim=1, stable=True).indices
-        thr = ops.noise_threshold(mag, order[:, :n_quiet].to(torch.int32).contiguous(), n_std_thresh)
-    else:
-        tc_frames = max(1, int(time_constant_s * sr / hop_length))
-        thr = ops.time_min(mag, tc_frames)
+    C = stft(x, **kw)   # a (rows, bins, frames) view of (rows, frames, bins) rows
+    ops = _Ops(C.device)
+    rows, bins, frames = C.shape
 
     gain = 10 ** (threshold_db / 20.0)
     if noise_profile is None and not stationary:
@@ -193,6 +208,31 @@ def spectral_gate(audio, noise_profile=None, *, sr: int = 22050, n_fft: int = 20
     if n_grad_freq > 1 or n_grad_time > 1:
         steps += [("f", int(n_grad_freq)), ("t", int(n_grad_time))]
     steps = [(a, n) for a, n in steps if n > 1]
+
+    # With a per-bin threshold (noise profile, or the stationary estimate) nothing needs the
+    # magnitudes as an array: energy, threshold and mask read the spectrum's own rows.
+    first_freq = steps[0][1] if steps and steps[0][0] == "f" else 1
+    spec_rows = C.transpose(1, 2)
+    direct = ((noise_profile is not None or stationary) and spec_rows.is_contiguous()
+              and first_freq <= _SPEC_MASK_MAX_WINDOW)
+    mag = None if direct else magnitude(C)
+
+    if noise_profile is not None:
+        noise = as_device_f32(noise_profile)
+        noise_mag = magnitude(stft(noise if noise.dim() > 1 else noise[None], **kw))
+        if noise_mag.shape[0] not in (1, rows):
+            raise ValueError(f"noise_profile has {noise_mag.shape[0]} rows, the audio {rows}")
+        thr = ops.noise_threshold(noise_mag, None, n_std_thresh)
+    elif stationary:
+        n_quiet = max(1, int(0.1 * frames))
+        energy = ops.frame_energy_spec(spec_rows) if direct else ops.frame_energy(mag)
+        quiet = torch.sort(energy, dim=1, stable=True).indices[:, :n_quiet].to(torch.int32).contiguous()
+        thr = (ops.noise_threshold_spec(spec_rows, quiet, n_std_thresh) if direct
+               else ops.noise_threshold(mag, quiet, n_std_thresh))
+    else:
+        tc_frames = max(1, int(time_constant_s * sr / hop_length))
+        thr = ops.time_min(mag, tc_frames)
+
     enhanced = ops.gate(mag, C, thr, gain, steps, False, prop_decrease)
     y = istft(enhanced, hop_length=hop_length, win_length=win_length, window=window, center=True,
               length=n_samples)

@@ -124,6 +124,43 @@ def test_tiled_kernels_on_small_and_ragged_shapes(gpu, shape):
         assert torch.equal(got, ops.apply_spectrum(spec_d, ops.box(ops.box(m, sf, 1), 1, st), False, 1.0))
 
 
+@pytest.mark.parametrize("shape", [(3, 65, 120), (1, 3, 2), (2, 1025, 44), (2, 33, 64), (1, 40, 1)])
+def test_steps_taken_from_the_spectrum(gpu, shape):
+    """Frame energy, noise threshold and mask + frequency average from the complex (rows, frames,
+    bins) spectrum against the same steps on its magnitude plane: threshold and mask bit for bit,
+    the energy (another summation order) to float32 rounding."""
+    from mlx_audio_amd.primitives import magnitude
+
+    rows, bins, frames = shape
+    rng = np.random.default_rng(bins * 7 + frames)
+    spec = (rng.standard_normal((rows, frames, bins)) + 1j * rng.standard_normal((rows, frames, bins))).astype(np.complex64)
+    spec_rows = _dev(spec, gpu)
+    mag = magnitude(spec_rows.transpose(1, 2))            # (rows, bins, frames) plane
+    ops = _Ops(gpu)
+    np.testing.assert_allclose(ops.frame_energy_spec(spec_rows).cpu().numpy(), ops.frame_energy(mag).cpu().numpy(),
+                               rtol=3e-6)
+    n_sel = max(1, frames // 3)
+    idx = _dev(np.stack([rng.permutation(frames)[:n_sel] for _ in range(rows)]).astype(np.int32), gpu)
+    for sel in (idx, None):
+        assert torch.equal(ops.noise_threshold_spec(spec_rows, sel, 1.5), ops.noise_threshold(mag, sel, 1.5))
+    for thr_rows in (rows, 1):
+        thr = _dev(np.abs(rng.standard_normal((thr_rows, bins))).astype(np.float32), gpu)
+        for size, keep in ((1, False), (2, True), (9, False), (33, True)):
+            assert torch.equal(ops.mask_box_spec(spec_rows, thr, 0.4, keep, 0.7, size),
+                               ops.mask_box(mag, thr, 0.4, keep, 0.7, size)), (thr_rows, size, keep)
+    lib = _lib.lib()
+    s = torch.cuda.current_stream(gpu).cuda_stream
+    out = torch.empty((rows, bins, frames), device=gpu)
+    thr = torch.ones((rows, bins), device=gpu)
+    assert lib.mia_gate_mask_box_spec(spec_rows.data_ptr(), thr.data_ptr(), rows, bins, frames, rows, 1.0, 0, 1.0,
+                                      34, out.data_ptr(), s) == _lib.MIA_ERR_UNSUPPORTED
+    assert lib.mia_gate_mask_box_spec(spec_rows.data_ptr(), thr.data_ptr(), rows, bins, frames, rows + 1, 1.0, 0, 1.0,
+                                      3, out.data_ptr(), s) == _lib.MIA_ERR_INVALID
+    assert lib.mia_frame_energy_spec(0, rows, bins, frames, out.data_ptr(), s) == _lib.MIA_ERR_INVALID
+    assert lib.mia_noise_threshold_spec(spec_rows.data_ptr(), rows, bins, frames, idx.data_ptr(), 0, 1.0,
+                                        out.data_ptr(), s) == _lib.MIA_ERR_INVALID
+
+
 def test_whole_mask_matches_the_oracle(gpu):
     """gate_mask of the oracle against the same sequence of launches on identical magnitudes."""
     rng = np.random.default_rng(2)
