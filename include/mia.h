@@ -359,6 +359,12 @@ int mia_polar(const float* mag, const float* angle, int64_t n, void* out, void* 
  * c_new, tprev, rebuilt: n complex64 values, mag: n floats, all in the same element order. */
 int mia_griffinlim_update(const void* c_new, const float* mag, void* tprev, void* rebuilt,
                           int64_t n, float momentum, void* stream);
+/* Set-up of the loop (griffinlim.py:118-123) in one pass: S and angle, device float (rows, bins,
+ * frames) with frames contiguous (angle may be NULL: phase zero), become mag_t: float (rows,
+ * frames, bins), and rebuilt = tprev = S * exp(i angle): complex64 (rows, frames, bins) - the
+ * order mia_istft / mia_stft / mia_griffinlim_update work in. */
+int mia_griffinlim_init(const float* S, const float* angle, int64_t rows, int64_t bins, int64_t frames,
+                        float* mag_t, void* rebuilt, void* tprev, void* stream);
 
 /* ---- spectral gating (primitives/spectral_gate.py) ------------------------------------
  * The host arithmetic the reference runs in NumPy / scipy.ndimage between its STFT and inverse

@@ -135,6 +135,8 @@ SIGNATURES = {
                                   c_int64, c_int64, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mia_spectrum_part": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_void_p]),
     "mia_transpose_spectrum": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p]),
+    "mia_griffinlim_init": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p,
+                                    c_void_p, c_void_p]),
     "mia_polar": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "mia_griffinlim_update": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float,
                                       c_void_p]),

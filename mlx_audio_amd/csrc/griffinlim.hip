@@ -103,6 +103,55 @@ __global__ __launch_bounds__(256) void spectrum_transpose_kernel(const float2* _
   }
 }
 
+// Set-up of the Griffin-Lim loop in one pass: the target magnitudes S and the initial phases,
+// both (rows, bins, frames) with frames contiguous as the reference holds them, become the loop's
+// state in the (rows, frames, bins) order the STFT kernels use - the magnitudes transposed, and
+// rebuilt = tprev = S * exp(i angle) (angle == nullptr: phase zero, S itself).  Tiles of 32 bins
+// x 64 frames through LDS, xcd_tile() order, rows along grid.z, block (32, 8).
+__global__ __launch_bounds__(256) void griffinlim_init_kernel(const float* __restrict__ S,
+                                                              const float* __restrict__ angle,
+                                                              long long bins, long long F,
+                                                              float* __restrict__ mag_t,
+                                                              float2* __restrict__ rebuilt,
+                                                              float2* __restrict__ tprev) {
+  __shared__ float2 tile[64][33];
+  __shared__ float mtile[64][33];
+  const long long row = blockIdx.z;
+  unsigned tile_f, tile_k;
+  if (!xcd_tile((unsigned)((F + 63) / 64), (unsigned)((bins + 31) / 32), tile_f, tile_k)) return;
+  const long long f0 = (long long)tile_f * 64, k0 = (long long)tile_k * 32;
+  const long long base = row * bins * F;
+  const int fx = threadIdx.y % 2 * 32 + threadIdx.x;  // frame within the tile: 64 per bin row
+#pragma unroll
+  for (int j = threadIdx.y / 2; j < 32; j += 4) {  // j: bin within the tile
+    const long long k = k0 + j, f = f0 + fx;
+    float m = 0.0f;
+    float2 z = {0.0f, 0.0f};
+    if (k < bins && f < F) {
+      m = S[base + k * F + f];
+      z = {m, 0.0f};
+      if (angle != nullptr) {
+        float sn, cs;
+        sincosf(angle[base + k * F + f], &sn, &cs);
+        z = {m * cs, m * sn};
+      }
+    }
+    mtile[fx][j] = m;
+    tile[fx][j] = z;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = threadIdx.y; j < 64; j += 8) {  // j: frame within the tile, x: bin
+    const long long f = f0 + j, k = k0 + threadIdx.x;
+    if (k < bins && f < F) {
+      const long long o = base + f * bins + k;
+      mag_t[o] = mtile[j][threadIdx.x];
+      rebuilt[o] = tile[j][threadIdx.x];
+      tprev[o] = tile[j][threadIdx.x];
+    }
+  }
+}
+
 }  // namespace mia
 
 extern "C" {
@@ -150,6 +199,27 @@ int mia_transpose_spectrum(const void* in, int64_t rows, int64_t bins, int64_t f
     hipLaunchKernelGGL(spectrum_transpose_kernel, dim3(xcd_tile_grid(tiles_f, tiles_k), 1, (unsigned)nr),
                        dim3(32, 8), 0, (hipStream_t)stream, (const float2*)in + (size_t)r0 * per_row,
                        (long long)bins, (long long)frames, (float2*)out + (size_t)r0 * per_row);
+  }
+  MIA_CHECK_HIP(hipGetLastError());
+  return MIA_OK;
+}
+
+int mia_griffinlim_init(const float* S, const float* angle, int64_t rows, int64_t bins, int64_t frames,
+                        float* mag_t, void* rebuilt, void* tprev, void* stream) {
+  using namespace mia;
+  MIA_REQUIRE(rows >= 0 && bins >= 0 && frames >= 0, "negative shape");
+  if (rows == 0 || bins == 0 || frames == 0) return MIA_OK;
+  MIA_REQUIRE(S && mag_t && rebuilt && tprev, "null pointer");
+  const unsigned tiles_f = (unsigned)((frames + 63) / 64), tiles_k = (unsigned)((bins + 31) / 32);
+  MIA_REQUIRE((unsigned long long)tiles_f * tiles_k < (1ULL << 28), "spectrogram too large for one launch");
+  const size_t per_row = (size_t)bins * (size_t)frames;
+  for (int64_t r0 = 0; r0 < rows; r0 += 65535) {  // a launch takes 65535 rows
+    const int64_t nr = rows - r0 < 65535 ? rows - r0 : 65535;
+    const size_t off = (size_t)r0 * per_row;
+    hipLaunchKernelGGL(griffinlim_init_kernel, dim3(xcd_tile_grid(tiles_f, tiles_k), 1, (unsigned)nr),
+                       dim3(32, 8), 0, (hipStream_t)stream, S + off, angle ? angle + off : nullptr,
+                       (long long)bins, (long long)frames, mag_t + off, (float2*)rebuilt + off,
+                       (float2*)tprev + off);
   }
   MIA_CHECK_HIP(hipGetLastError());
   return MIA_OK;

@@ -84,14 +84,20 @@ def griffinlim(S, n_iter: int = 32, hop_length=None, win_length=None, n_fft=None
         ang = rng.uniform(-np.pi, np.pi, (rows, bins, frames)).astype(np.float32)
         angles = torch.from_numpy(ang).to(S.device)
     elif init == "zeros":
-        angles = torch.zeros((rows, bins, frames), dtype=torch.float32, device=S.device)
+        angles = None
     else:
         raise ValueError(f"Unknown init: '{init}'. Supported: 'random', 'zeros'")
 
-    # everything below lives in (rows, frames, bins) order
-    mag_t = S.transpose(1, 2).contiguous()
-    rebuilt = _polar(mag_t, angles.transpose(1, 2).contiguous())
-    tprev = rebuilt.clone()
+    # everything below lives in (rows, frames, bins) order: one pass transposes the magnitudes and
+    # builds the first estimate (and its copy, the "previous" one of the momentum term)
+    Sc = S.contiguous()
+    mag_t = torch.empty((rows, frames, bins), dtype=torch.float32, device=S.device)
+    rebuilt = torch.empty((rows, frames, bins), dtype=torch.complex64, device=S.device)
+    tprev = torch.empty_like(rebuilt)
+    with torch.cuda.device(S.device):
+        _lib.check(_lib.lib().mia_griffinlim_init(Sc.data_ptr(), 0 if angles is None else angles.data_ptr(),
+                                                  rows, bins, frames, mag_t.data_ptr(), rebuilt.data_ptr(),
+                                                  tprev.data_ptr(), stream_ptr(S.device)))
     kw = dict(hop_length=hop_length, win_length=win_length, n_fft=n_fft, window=window,
               center=center)
     # With centre padding by zeros the trimmed signal, padded again, is the untrimmed

@@ -123,3 +123,32 @@ def test_c_abi_checks(gpu):
     assert lib.mia_polar(m.data_ptr(), m.data_ptr(), 8, out.data_ptr(), s) == _lib.MIA_OK
     torch.cuda.synchronize()
     np.testing.assert_allclose(out.cpu().numpy(), np.exp(1j), rtol=1e-6)
+
+
+@pytest.mark.parametrize("shape", [(2, 257, 65), (1, 33, 1), (3, 5, 130), (1, 1025, 44)])
+def test_set_up_in_one_pass(gpu, shape):
+    """mia_griffinlim_init: transposed magnitudes and S * exp(i angle) (twice: estimate and previous
+    estimate) in the loop's (rows, frames, bins) order, against mia_polar on transposed copies."""
+    from mlx_audio_amd import _lib
+    from mlx_audio_amd.primitives.griffinlim import _polar
+
+    rows, bins, frames = shape
+    rng = np.random.default_rng(bins)
+    S = _dev(np.abs(rng.standard_normal(shape)).astype(np.float32), gpu)
+    ang = _dev(rng.uniform(-np.pi, np.pi, shape).astype(np.float32), gpu)
+    lib = _lib.lib()
+    s = torch.cuda.current_stream(gpu).cuda_stream
+    for angles in (ang, None):
+        mag_t = torch.full((rows, frames, bins), -1.0, device=gpu)
+        reb = torch.full((rows, frames, bins), complex(9, 9), dtype=torch.complex64, device=gpu)
+        prev = torch.full_like(reb, complex(8, 8))
+        _lib.check(lib.mia_griffinlim_init(S.data_ptr(), 0 if angles is None else angles.data_ptr(), rows, bins,
+                                           frames, mag_t.data_ptr(), reb.data_ptr(), prev.data_ptr(), s))
+        want_mag = S.transpose(1, 2).contiguous()
+        want = _polar(want_mag, (ang if angles is not None else torch.zeros_like(ang)).transpose(1, 2).contiguous())
+        assert torch.equal(mag_t, want_mag)
+        assert torch.equal(torch.view_as_real(reb), torch.view_as_real(want))
+        assert torch.equal(torch.view_as_real(prev), torch.view_as_real(want))
+    assert lib.mia_griffinlim_init(0, 0, rows, bins, frames, mag_t.data_ptr(), reb.data_ptr(), prev.data_ptr(), s) \
+        == _lib.MIA_ERR_INVALID
+
