@@ -461,6 +461,16 @@ int mia_normalize_cac_sums(const void* spec, int64_t batch, int channels, int64_
  * Nyquist bin it dropped) and the pad_frames frames on either side (HTDemucs: two) zero. */
 int mia_cac_to_spectrum(const float* planes, int64_t rows, int64_t bins, int64_t frames, int pad_bins,
                         int pad_frames, void* out, void* stream);
+/* The waveform side of the same fusion (model.py:231-233, 378-390): mia_pad_rows_moments writes
+ * out[row] = zero_left zeros, x[row, :n], zero_right zeros (the padding HTDemucs applies before its
+ * STFT) and, from the same read, adds the sum and the sum of squares of x over each group of `group`
+ * consecutive rows into sums: device (rows / group, 2) doubles, zeroed by the call.
+ * mia_normalize_rows_sums is mia_normalize_rows with those sums given (rows = the groups, n = group
+ * times the row length). */
+int mia_pad_rows_moments(const float* x, int64_t rows, int64_t n, int64_t zero_left, int64_t zero_right,
+                         int group, float* out, void* sums, void* stream);
+int mia_normalize_rows_sums(const float* x, int64_t rows, int64_t n, float eps, float* out, float* stats,
+                            const void* sums, void* stream);
 
 /* ---- Whisper encoder stem (models/whisper/layers/encoder.py:72-109) ----------------------
  * What AudioEncoder.__call__ does before its transformer blocks: x = mel^T (frames, n_mels);

@@ -128,6 +128,10 @@ SIGNATURES = {
                                    c_void_p]),
     "mia_stft_moments": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_float, c_void_p, c_int, c_int,
                                  c_int64, c_int64, c_void_p, c_void_p]),
+    "mia_pad_rows_moments": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_int, c_void_p, c_void_p,
+                                     c_void_p]),
+    "mia_normalize_rows_sums": (c_int, [c_void_p, c_int64, c_int64, c_float, c_void_p, c_void_p, c_void_p,
+                                        c_void_p]),
     "mia_cac_to_spectrum": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p]),
     "mia_normalize_cac_sums": (c_int, [c_void_p, c_int64, c_int, c_int64, c_int64, c_int64, c_int64,
                                        c_int64, c_int64, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),

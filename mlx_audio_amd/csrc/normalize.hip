@@ -76,6 +76,46 @@ __global__ __launch_bounds__(256) void cac_moments_kernel(const float2* __restri
   block_accumulate(s, q, sums + 2 * b);
 }
 
+// out[row, :] = zero_left zeros, x[row, :], zero_right zeros (what HTDemucs pads its waveform with
+// before the STFT), and on the way the sum and sum of squares of x over each group of `group`
+// consecutive rows (a batch item's channels) added to sums[2 * (row / group)] - the moments the
+// waveform's normalisation needs, from the one pass that has to read the waveform anyway.
+// grid (chunks, rows).
+__global__ __launch_bounds__(256) void pad_rows_moments_kernel(const float* __restrict__ x, long long n,
+                                                               long long zero_left, long long zero_right,
+                                                               int group, float* __restrict__ out,
+                                                               double* __restrict__ sums) {
+  const long long row = blockIdx.y;
+  const long long np = zero_left + n + zero_right;
+  const float* __restrict__ line = x + row * n;
+  float* __restrict__ dst = out + row * np;
+  const long long stride = (long long)gridDim.x * 256;
+  const long long start = (long long)blockIdx.x * 256 + threadIdx.x;
+  for (long long i = start; i < zero_left; i += stride) dst[i] = 0.0f;
+  for (long long i = start; i < zero_right; i += stride) dst[zero_left + n + i] = 0.0f;
+  double s4[4] = {0.0, 0.0, 0.0, 0.0}, q4[4] = {0.0, 0.0, 0.0, 0.0};
+  long long i = start;
+  for (; i + 3 * stride < n; i += 4 * stride) {
+    float v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = line[i + k * stride];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      dst[zero_left + i + k * stride] = v[k];
+      s4[k] += (double)v[k];
+      q4[k] += (double)v[k] * (double)v[k];
+    }
+  }
+  for (; i < n; i += stride) {
+    const float v = line[i];
+    dst[zero_left + i] = v;
+    s4[0] += (double)v;
+    q4[0] += (double)v * (double)v;
+  }
+  block_accumulate((s4[0] + s4[1]) + (s4[2] + s4[3]), (q4[0] + q4[1]) + (q4[2] + q4[3]),
+                   sums + 2 * (row / group));
+}
+
 __device__ __forceinline__ void mean_std(const double* __restrict__ sums, double count, float eps,
                                          float& mean, float& inv) {
   const double m = sums[0] / count;
@@ -255,8 +295,8 @@ __global__ __launch_bounds__(256) void cac_to_spectrum_kernel(const float* __res
 
 extern "C" {
 
-int mia_normalize_rows(const float* x, int64_t rows, int64_t n, float eps, float* out, float* stats,
-                       void* sums, void* stream) {
+static int normalize_rows(const float* x, int64_t rows, int64_t n, float eps, float* out, float* stats,
+                          void* sums, int have_sums, void* stream) {
   using namespace mia;
   MIA_REQUIRE(rows >= 0 && n >= 1, "rows and n must be >= 0 and 1");
   if (rows == 0) return MIA_OK;
@@ -264,21 +304,23 @@ int mia_normalize_rows(const float* x, int64_t rows, int64_t n, float eps, float
   if (rows > 65535) {  // a launch takes 65535 rows: the rest follows in further launches
     for (int64_t r0 = 0; r0 < rows; r0 += 65535) {
       const int64_t nr = rows - r0 < 65535 ? rows - r0 : 65535;
-      const int rc = mia_normalize_rows(x + (size_t)r0 * n, nr, n, eps, out + (size_t)r0 * n,
-                                        stats + 2 * (size_t)r0, (double*)sums + 2 * (size_t)r0, stream);
+      const int rc = normalize_rows(x + (size_t)r0 * n, nr, n, eps, out + (size_t)r0 * n,
+                                    stats + 2 * (size_t)r0, (double*)sums + 2 * (size_t)r0, have_sums, stream);
       if (rc != MIA_OK) return rc;
     }
     return MIA_OK;
   }
   hipStream_t s = (hipStream_t)stream;
-  MIA_CHECK_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 2 * (size_t)rows, s));
+  if (!have_sums) MIA_CHECK_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 2 * (size_t)rows, s));
   // about 2048 workgroups in all: enough to fill the device, few enough that the two atomics
   // each of them ends with do not queue up on a row's pair of sums
   long long chunks = (n + 256 * 16 - 1) / (256 * 16);
   const long long cap = 2048 / rows > 1 ? 2048 / rows : 1;
   if (chunks > cap) chunks = cap;
   const dim3 grid((unsigned)chunks, (unsigned)rows);
-  hipLaunchKernelGGL(row_moments_kernel, grid, dim3(256), 0, s, x, (long long)n, (double*)sums);
+  if (!have_sums) {
+    hipLaunchKernelGGL(row_moments_kernel, grid, dim3(256), 0, s, x, (long long)n, (double*)sums);
+  }
   hipLaunchKernelGGL(row_normalize_kernel, grid, dim3(256), 0, s, x, (long long)n,
                      (const double*)sums, eps, out, stats);
   MIA_CHECK_HIP(hipGetLastError());
@@ -380,6 +422,41 @@ int mia_cac_to_spectrum(const float* planes, int64_t rows, int64_t bins, int64_t
     hipLaunchKernelGGL(cac_to_spectrum_kernel, dim3(xcd_tile_grid(tiles_t, tiles_f), 1, (unsigned)nr),
                        dim3(32, 8), 0, (hipStream_t)stream, planes + (size_t)r0 * in_row, (long long)bins,
                        (long long)frames, pad_bins, pad_frames, (float2*)out + (size_t)r0 * out_row);
+  }
+  MIA_CHECK_HIP(hipGetLastError());
+  return MIA_OK;
+}
+
+int mia_normalize_rows(const float* x, int64_t rows, int64_t n, float eps, float* out, float* stats,
+                       void* sums, void* stream) {
+  return normalize_rows(x, rows, n, eps, out, stats, sums, 0, stream);
+}
+
+int mia_normalize_rows_sums(const float* x, int64_t rows, int64_t n, float eps, float* out, float* stats,
+                            const void* sums, void* stream) {
+  return normalize_rows(x, rows, n, eps, out, stats, const_cast<void*>(sums), 1, stream);
+}
+
+int mia_pad_rows_moments(const float* x, int64_t rows, int64_t n, int64_t zero_left, int64_t zero_right,
+                         int group, float* out, void* sums, void* stream) {
+  using namespace mia;
+  MIA_REQUIRE(rows >= 0 && n >= 1 && zero_left >= 0 && zero_right >= 0, "negative shape");
+  MIA_REQUIRE(group >= 1 && group <= 65535 && rows % group == 0,
+              "the %lld rows do not split into groups of %d (at most 65535 rows per group)", (long long)rows, group);
+  if (rows == 0) return MIA_OK;
+  MIA_REQUIRE(x && out && sums, "null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  MIA_CHECK_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 2 * (size_t)(rows / group), s));
+  const size_t np = (size_t)(zero_left + n + zero_right);
+  for (int64_t r0 = 0; r0 < rows; r0 += 65535 / group * group) {  // whole groups per launch
+    const int64_t step = 65535 / group * group;
+    const int64_t nr = rows - r0 < step ? rows - r0 : step;
+    long long chunks = (n + 256 * 16 - 1) / (256 * 16);
+    const long long cap = 4096 / nr > 1 ? 4096 / nr : 1;
+    if (chunks > cap) chunks = cap;
+    hipLaunchKernelGGL(pad_rows_moments_kernel, dim3((unsigned)chunks, (unsigned)nr), dim3(256), 0, s,
+                       x + (size_t)r0 * n, (long long)n, (long long)zero_left, (long long)zero_right, group,
+                       out + (size_t)r0 * np, (double*)sums + 2 * (size_t)(r0 / group));
   }
   MIA_CHECK_HIP(hipGetLastError());
   return MIA_OK;

@@ -31,19 +31,28 @@ def _spec_and_sums(x, n_fft: int, hop_length: int, want_sums: bool):
     """htdemucs_spec, and with want_sums (compiled FFT sizes) the per-item sums the input
     normalisation needs - sum and sum of squares of the real and imaginary parts of the kept
     bins and frames - accumulated by the STFT kernel while the spectrum is still in registers.
-    Returns (spec, sums or None)."""
+    Returns (spec, sums or None, sums of the waveform or None)."""
     x = as_device_f32(x, ndim_allowed=(3,))
     B, C, T = x.shape
     le = int(math.ceil(T / hop_length))
     pad = hop_length // 2 * 3
-    # the zero margins written by themselves: a pad() would first fill the whole buffer
     right = pad + le * hop_length - T
     xp = torch.empty((B, C, pad + T + right), dtype=x.dtype, device=x.device)
-    xp[..., :pad].zero_()
-    xp[..., pad + T:].zero_()
-    xp[..., pad:pad + T].copy_(x)
-    scale = 1.0 / math.sqrt(n_fft)
     lib = _lib.lib()
+    mix_sums = None
+    if want_sums:
+        # the padded copy also adds up the waveform's own moments (its normalisation needs them)
+        mix_sums = torch.empty((B, 2), dtype=torch.float64, device=x.device)
+        xc = x.contiguous()
+        with torch.cuda.device(x.device):
+            _lib.check(lib.mia_pad_rows_moments(xc.data_ptr(), B * C, T, pad, right, C, xp.data_ptr(),
+                                                mix_sums.data_ptr(), stream_ptr(x.device)))
+    else:
+        # the zero margins written by themselves: a pad() would first fill the whole buffer
+        xp[..., :pad].zero_()
+        xp[..., pad + T:].zero_()
+        xp[..., pad:pad + T].copy_(x)
+    scale = 1.0 / math.sqrt(n_fft)
     sums = None
     if want_sums and lib.mia_fft_size_supported(n_fft):
         rows = xp.reshape(B * C, -1)
@@ -59,7 +68,7 @@ def _spec_and_sums(x, n_fft: int, hop_length: int, want_sums: bool):
         raw = _stft_raw(xp.reshape(B * C, -1), n_fft, hop_length, n_fft, "hann", True, "reflect",
                         scale=scale)                       # (B*C, frames, bins)
     spec = raw.transpose(1, 2)[:, :-1, 2:2 + le]           # (B*C, n_fft//2, le)
-    return spec.unflatten(0, (B, C)), sums
+    return spec.unflatten(0, (B, C)), sums, mix_sums
 
 
 def htdemucs_ispec(m, length: int, n_fft: int = DEMUCS_N_FFT,
@@ -99,9 +108,9 @@ def htdemucs_normalize(mix, spec=None, eps: float = 1e-5):
     reference, where they are used later to undo the normalisation (model.py:349, 367).
     """
     mix = as_device_f32(mix, ndim_allowed=(3,))
-    spec_sums = None
+    spec_sums = mix_sums = None
     if spec is None:
-        spec, spec_sums = _spec_and_sums(mix, DEMUCS_N_FFT, DEMUCS_HOP_LENGTH, True)
+        spec, spec_sums, mix_sums = _spec_and_sums(mix, DEMUCS_N_FFT, DEMUCS_HOP_LENGTH, True)
     if spec.dim() != 4 or spec.dtype != torch.complex64:
         raise ValueError("spec must be a complex64 [B, C, F, Tf] tensor")
     B, C, T = mix.shape
@@ -125,7 +134,11 @@ def htdemucs_normalize(mix, spec=None, eps: float = 1e-5):
             _lib.check(lib.mia_normalize_cac(base, B, Cs, F, Tf, sb, sc, sf, st, float(eps),
                                              freq_in.data_ptr(), s_stats.data_ptr(), sums.data_ptr(),
                                              stream))
-        _lib.check(lib.mia_normalize_rows(mix.data_ptr(), B, C * T, float(eps), mix_norm.data_ptr(),
-                                          m_stats.data_ptr(), sums.data_ptr(), stream))
+        if mix_sums is not None:    # added up while the waveform was padded for the STFT
+            _lib.check(lib.mia_normalize_rows_sums(mix.data_ptr(), B, C * T, float(eps), mix_norm.data_ptr(),
+                                                   m_stats.data_ptr(), mix_sums.data_ptr(), stream))
+        else:
+            _lib.check(lib.mia_normalize_rows(mix.data_ptr(), B, C * T, float(eps), mix_norm.data_ptr(),
+                                              m_stats.data_ptr(), sums.data_ptr(), stream))
     return (freq_in, s_stats[:, 0].reshape(B, 1, 1, 1), s_stats[:, 1].reshape(B, 1, 1, 1),
             mix_norm, m_stats[:, 0].reshape(B, 1, 1), m_stats[:, 1].reshape(B, 1, 1))

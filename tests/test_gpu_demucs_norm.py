@@ -159,3 +159,30 @@ def test_ispec_equals_the_inverse_stft_of_the_assembled_spectrum(gpu):
     assert got.shape == (B, S, C, length)
     np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=0, atol=2e-5 * float(want.abs().max()))
 
+
+@pytest.mark.parametrize("rows,group,n,zl,zr", [(4, 2, 44100, 1536, 1700), (6, 3, 1000, 0, 0), (2, 1, 1, 5, 0), (8, 8, 70001, 3, 9)])
+def test_padded_copy_with_moments(gpu, rows, group, n, zl, zr):
+    """mia_pad_rows_moments: the zero-padded copy bit for bit, the sums of each group of rows against
+    double-precision sums; mia_normalize_rows_sums with them equals mia_normalize_rows."""
+    rng = np.random.default_rng(rows * 10 + group)
+    x = _dev((rng.standard_normal((rows, n)) * (1 + np.arange(rows))[:, None] + 0.3).astype(np.float32), gpu)
+    lib = _lib.lib()
+    s = torch.cuda.current_stream(gpu).cuda_stream
+    out = torch.full((rows, zl + n + zr), 7.0, device=gpu)
+    sums = torch.full((rows // group, 2), 5.0, dtype=torch.float64, device=gpu)
+    _lib.check(lib.mia_pad_rows_moments(x.data_ptr(), rows, n, zl, zr, group, out.data_ptr(), sums.data_ptr(), s))
+    assert torch.equal(out, torch.nn.functional.pad(x, (zl, zr)))
+    xd = x.to(torch.float64).reshape(rows // group, -1)
+    np.testing.assert_allclose(sums[:, 0].cpu().numpy(), xd.sum(dim=1).cpu().numpy(), rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(sums[:, 1].cpu().numpy(), (xd * xd).sum(dim=1).cpu().numpy(), rtol=1e-11)
+    g, m = rows // group, group * n
+    a, b = torch.empty((g, m), device=gpu), torch.empty((g, m), device=gpu)
+    sa, sb = torch.empty((g, 2), device=gpu), torch.empty((g, 2), device=gpu)
+    scratch = torch.empty((g, 2), dtype=torch.float64, device=gpu)
+    _lib.check(lib.mia_normalize_rows(x.data_ptr(), g, m, 1e-5, a.data_ptr(), sa.data_ptr(), scratch.data_ptr(), s))
+    _lib.check(lib.mia_normalize_rows_sums(x.data_ptr(), g, m, 1e-5, b.data_ptr(), sb.data_ptr(), sums.data_ptr(), s))
+    np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(sb.cpu().numpy(), sa.cpu().numpy(), rtol=1e-6)
+    assert lib.mia_pad_rows_moments(x.data_ptr(), rows, n, zl, zr, rows + 1, out.data_ptr(), sums.data_ptr(), s) \
+        == _lib.MIA_ERR_INVALID
+
