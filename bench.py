@@ -218,7 +218,7 @@ KERNEL_OF = {
     "clap64": "fwd_kernel<1024, mel> (fused pad+frame+window+rFFT+mel+dB)",
     "mfcc40": "fwd_kernel<2048, mel> (fused rFFT+mel+dB) followed by dct2_mfma_kernel",
     "htdemucs": "fwd_kernel<4096> then istft_own_kernel<4096> (fused inverse FFT + overlap-add)",
-    "resample": "upfirdn_kernel (polyphase FIR, input span and phase table staged in LDS)",
+    "resample": "upfirdn_shared_kernel (polyphase FIR: input span staged in LDS, sample windows shared between adjacent outputs in registers, taps through the scalar cache)",
     "contrast": "spectral_contrast_kernel<16> (one thread per frame, sorted register arrays)",
     "demucs_front": "fwd_kernel<4096> + cac_moments_kernel + cac_normalize_kernel + row kernels",
     "spectral_gate": "fwd_kernel<2048> + magnitude + energy / threshold / mask kernels + gate_apply_spectrum_kernel + istft_own_kernel<2048>",

@@ -259,6 +259,16 @@ int mia_spectrum_part(const void* z, int64_t rows, int64_t frames, int64_t bins,
 int mia_upfirdn(const float* x, int64_t rows, int64_t n_in, const float* phase_table, int up,
                 int down, int taps_per_phase, int64_t skip, int64_t n_out, int pad_mode, float* out,
                 void* stream);
+/* The same filter (primitives/resample.py:275) by the kernel that shares a lane's sample window
+ * between adjacent outputs: same arguments and the same bits out, but the phase table's
+ * rows carry `margin` zeros in front of and behind their taps_per_phase taps — device
+ * (up, margin + taps_per_phase + margin).  mia_upfirdn_margin returns the margin this kernel
+ * needs for the ratio, or 0 when it does not apply (lane spacing that meets in one LDS bank,
+ * spans beyond the LDS, rows shorter than one run of outputs): then call mia_upfirdn. */
+int mia_upfirdn_margin(int up, int down, int taps_per_phase, int64_t n_out);
+int mia_upfirdn_shared(const float* x, int64_t rows, int64_t n_in, const float* padded_table,
+                       int margin, int up, int down, int taps_per_phase, int64_t skip,
+                       int64_t n_out, int pad_mode, float* out, void* stream);
 /* resample(res_type="linear") (primitives/resample.py:171-196): out[r,i] =
  * float(((1-f)*x[r,lo] + f*x[r,min(lo+1,n_in-1)]) * gain) in float64, at position
  * i*step (the last output sits exactly on n_in-1), lo = floor, f = fraction.

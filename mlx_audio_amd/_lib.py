@@ -95,6 +95,9 @@ SIGNATURES = {
     "mia_phase": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "mia_upfirdn": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int, c_int, c_int, c_int64,
                             c_int64, c_int, c_void_p, c_void_p]),
+    "mia_upfirdn_margin": (c_int, [c_int, c_int, c_int, c_int64]),
+    "mia_upfirdn_shared": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int, c_int, c_int, c_int,
+                                   c_int64, c_int64, c_int, c_void_p, c_void_p]),
     "mia_resample_linear": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_double, c_double,
                                     c_void_p, c_void_p]),
     "mia_spectral_stat": (c_int, [c_void_p, c_int64, c_int, c_int64, c_void_p, c_void_p, c_int,

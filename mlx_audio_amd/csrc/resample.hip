@@ -170,6 +170,338 @@ __global__ __launch_bounds__(1024) void upfirdn_kernel(
   }
 }
 
+// ---- Polyphase filter with the sample window shared in registers ---------------------------
+//
+// Outputs `up` apart use the same filter phase, and their sample windows lie `down` apart.
+// Here a lane takes a sub-run of U = c * up consecutive outputs and the 64 lanes of a wave take
+// 64 consecutive sub-runs, so at any moment all lanes of a wave work on the same phase: the
+// taps are wave-uniform and come through the scalar path, and the lanes' sample addresses are
+// c * down apart (odd, or 2 mod 4: no or two-way bank conflicts).  A wave-step produces R (4 or
+// 5) adjacent outputs per lane: their windows overlap almost completely, so the lane reads the
+// union once (16 samples at a time) and every sample feeds all R accumulators — a quarter of
+// the LDS reads of one read per tap, none of them for taps.  Output j of the R starts d_j
+// samples later than output 0; its taps are addressed as h[s - d_j] in a table whose rows carry
+// `margin` zeros on both sides, so positions outside an output's own window add x * 0 = +-0 to
+// a sum that is never -0: the result is the same float32 sum, oldest sample first, as long as
+// the samples are finite.  Runs whose staged span holds an infinity or a NaN (where x * 0
+// would differ from skipping the product) take a plain per-output loop instead.
+//
+// While a run is computed the next run's span is already on its way into registers.
+
+constexpr int kShChunk = 16;  // samples per chunk of a wave-step (two half-chunks of eight)
+constexpr int kShPre = 8;    // 16-byte loads per thread that hold the next run's span
+constexpr int kShBt = 12;    // ints per wave-step in the table of step constants
+
+struct ShRun {
+  long long row, o0, x_first;
+  unsigned ph0;
+  int cnt, span, lead, quads;
+};
+
+__device__ __forceinline__ ShRun sh_run(long long item, long long runs_per_row, int run,
+                                        long long n_out, long long skip, int up, int down, int P,
+                                        int over, const float* __restrict__ x, long long n_in) {
+  ShRun r;
+  r.row = item / runs_per_row;
+  r.o0 = (item - r.row * runs_per_row) * run;
+  const long long rem = n_out - r.o0;
+  r.cnt = rem < run ? (int)rem : run;
+  const long long q0 = (r.o0 + skip) * down;
+  const long long xq0 = q0 / up;
+  r.ph0 = (unsigned)(q0 - xq0 * up);
+  r.x_first = xq0 - P + 1;
+  const unsigned q_last = r.ph0 + (unsigned)(r.cnt - 1) * (unsigned)down;
+  // `over` samples behind the last window are read too (with zero taps): they must be staged,
+  // so that they are finite or seen not to be
+  r.span = (int)(q_last / (unsigned)up) + P + over;
+  const float* xr = x + r.row * n_in;
+  r.lead = (int)(((uintptr_t)(xr + r.x_first) >> 2) & 3);
+  r.quads = (r.span + r.lead + 3) >> 2;
+  return r;
+}
+
+typedef float tap8 __attribute__((ext_vector_type(8)));
+typedef float smp2 __attribute__((ext_vector_type(2)));
+
+// Eight consecutive floats at base + byte_off, both wave-uniform, through the scalar cache.
+__device__ __forceinline__ void tap_load(tap8& dst, const float* base, unsigned byte_off) {
+  asm volatile("s_load_dwordx8 %0, %1, %2" : "=s"(dst) : "s"(base), "s"(byte_off));
+}
+
+// Eight consecutive floats of LDS at a per-lane byte address (4-byte aligned).
+__device__ __forceinline__ void smp_load(smp2 (&d)[4], unsigned lds_byte_addr) {
+  asm volatile(
+      "ds_read2_b32 %0, %4 offset1:1\n\tds_read2_b32 %1, %4 offset0:2 offset1:3\n\t"
+      "ds_read2_b32 %2, %4 offset0:4 offset1:5\n\tds_read2_b32 %3, %4 offset0:6 offset1:7"
+      : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3])
+      : "v"(lds_byte_addr));
+}
+
+template <int R>
+__device__ __forceinline__ void tap_wait(tap8 (&t)[R], smp2 (&d)[4]) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(t[0]), "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]));
+#pragma unroll
+  for (int j = 1; j < R; ++j) asm volatile("" : "+s"(t[j]));  // stays behind the wait
+}
+
+__device__ __forceinline__ bool not_finite4(const float4 v) {
+  return !(__builtin_isfinite(v.x) && __builtin_isfinite(v.y) && __builtin_isfinite(v.z) &&
+           __builtin_isfinite(v.w));
+}
+
+// Samples a .. a+3 of the row (a is a multiple of four samples from a 16-byte boundary): one
+// 16-byte load when they lie inside the row, else sample by sample with the signal extension.
+__device__ __forceinline__ float4 sh_quad(const float* __restrict__ xr, long long n_in, long long a,
+                                          int mode) {
+  if (a >= 0 && a + 4 <= n_in) return *reinterpret_cast<const float4*>(xr + a);
+  return make_float4(extended_sample(xr, n_in, a, mode), extended_sample(xr, n_in, a + 1, mode),
+                     extended_sample(xr, n_in, a + 2, mode), extended_sample(xr, n_in, a + 3, mode));
+}
+
+template <int R>
+__global__ __launch_bounds__(1024) void upfirdn_shared_kernel(
+    const float* __restrict__ x, long long n_in, const float* __restrict__ table, int up, int down,
+    int P, int margin, long long skip, long long n_out, int mode, float* __restrict__ out, int U,
+    int cd, int span_cap, long long runs_per_row, long long total_runs, int runs_per_wg) {
+  extern __shared__ __attribute__((aligned(16))) float rs_smem[];
+  float* xs = rs_smem;
+  int* bt = reinterpret_cast<int*>(rs_smem + span_cap);  // per wave-step constants, kShBt ints each
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nw = nthr >> 6;
+  const int PP = P + 2 * margin;
+  const int run = 64 * U;
+  const int nblocks = (U + R - 1) / R;
+  volatile int* flag = bt + nblocks * kShBt;
+  if (tid == 0) *flag = -1;  // runs are numbered from 0
+  // A run is a multiple of `up` outputs, so every run starts on the same filter phase, and the
+  // phases and sample offsets of a wave-step's R outputs are the same in every run: worked out
+  // once.  Entry jj < R: byte offset into the table of the taps that go with the step's sample
+  // position 0 for output jj (row * pitch + margin - d_jj); entry 8: the step's first sample,
+  // relative to the lane's; entry 9: its number of chunks.
+  {
+    const unsigned ph0 = (unsigned)((skip * down) % up);
+    const unsigned ddiv = (unsigned)down / (unsigned)up, dmod = (unsigned)down % (unsigned)up;
+    for (int jb = tid; jb < nblocks; jb += nthr) {
+      const unsigned qj = ph0 + (unsigned)(jb * R) * (unsigned)down;
+      unsigned xi = qj / (unsigned)up;
+      unsigned t = qj - xi * (unsigned)up;
+      const unsigned xi0 = xi;
+      int dlast = 0;
+      for (int jj = 0; jj < R; ++jj) {
+        dlast = (int)(xi - xi0);
+        bt[jb * kShBt + jj] = 4 * ((int)t * PP + margin - dlast);
+        t += dmod;
+        xi += ddiv;
+        if (t >= (unsigned)up) {
+          t -= (unsigned)up;
+          ++xi;
+        }
+      }
+      bt[jb * kShBt + 8] = (int)xi0;
+      bt[jb * kShBt + 9] = (P + dlast + kShChunk - 1) / kShChunk;
+    }
+  }
+  __syncthreads();
+
+  const long long first = (long long)blockIdx.x * runs_per_wg;
+  const long long last = first + runs_per_wg < total_runs ? first + runs_per_wg : total_runs;
+  float4 pre[kShPre];
+#pragma unroll
+  for (int k = 0; k < kShPre; ++k) pre[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+  bool have_pre = false;
+  for (long long item = first; item < last; ++item) {
+    const int id = (int)(item - first);
+    const ShRun r = sh_run(item, runs_per_row, run, n_out, skip, up, down, P, margin, x, n_in);
+    const float* __restrict__ xr = x + r.row * n_in;
+
+    // the run's span of samples into LDS, 16 bytes at a time from a 16-byte boundary of the
+    // row (`lead` samples early): from the registers filled during the previous run, else
+    // fetched here; a thread that meets a non-finite sample marks the run
+    bool bad = false;
+    const int shift = r.lead;
+    {
+      float4* dst = reinterpret_cast<float4*>(xs);
+      if (have_pre) {
+#pragma unroll
+        for (int k = 0; k < kShPre; ++k) {
+          const int i = tid + k * nthr;
+          if (i < r.quads) {
+            dst[i] = pre[k];
+            bad |= not_finite4(pre[k]);
+          }
+        }
+      } else {
+        for (int i = tid; i < r.quads; i += nthr) {
+          const float4 v = sh_quad(xr, n_in, r.x_first - r.lead + 4LL * i, mode);
+          dst[i] = v;
+          bad |= not_finite4(v);
+        }
+      }
+    }
+    if (bad) *flag = id;
+    __syncthreads();
+    const bool plain = __builtin_amdgcn_readfirstlane(*flag) == id;
+
+    have_pre = false;
+    if (item + 1 < last) {
+      const ShRun nx = sh_run(item + 1, runs_per_row, run, n_out, skip, up, down, P, margin, x, n_in);
+      if (nx.quads <= kShPre * nthr) {
+        const float* __restrict__ nr = x + nx.row * n_in;
+#pragma unroll
+        for (int k = 0; k < kShPre; ++k) {
+          const int i = tid + k * nthr;
+          if (i < nx.quads) pre[k] = sh_quad(nr, n_in, nx.x_first - nx.lead + 4LL * i, mode);
+        }
+        have_pre = true;
+      }
+    }
+
+    float* __restrict__ orow = out + r.row * n_out + r.o0;
+    if (!plain) {
+      const float* xl = xs + shift + lane * cd;
+      for (int jb = wave; jb < nblocks; jb += nw) {
+        // the step's constants (wave-uniform: through the scalar registers)
+        const int* bc = bt + jb * kShBt;
+        const int xi0 = __builtin_amdgcn_readfirstlane(bc[8]);
+        const int nch = __builtin_amdgcn_readfirstlane(bc[9]);
+        float acc[R];
+#pragma unroll
+        for (int jj = 0; jj < R; ++jj) acc[jj] = 0.0f;
+        // Taps (scalar loads, eight per output) and samples (LDS reads, eight per lane) come in
+        // two sets that take turns, each requested one half-chunk (8 R multiply-adds) before
+        // its use.  Scalar loads return out of order, so the only wait there is is "all of
+        // them", placed after the arithmetic that covers it.  Loads and waits are invisible
+        // to the compiler (it would wait right behind each load); a wait names the registers
+        // it makes valid, so that no use can move in front of it, and every request names a
+        // register of the arithmetic that has to stay behind it.
+        unsigned xa = (unsigned)(unsigned long long)(xl + xi0);  // LDS byte address of the window
+        const float* pa = table;
+        const float* pb = table + 8;
+        tap8 ta[R], tb[R];
+        smp2 va[4], vb[4];
+        unsigned hb[R];
+#pragma unroll
+        for (int jj = 0; jj < R; ++jj) hb[jj] = (unsigned)__builtin_amdgcn_readfirstlane(bc[jj]);
+#pragma unroll
+        for (int jj = 0; jj < R; ++jj) tap_load(ta[jj], pa, hb[jj]);
+        smp_load(va, xa);
+        for (int c = 0; c < nch; ++c) {
+          tap_wait(ta, va);
+          pa += kShChunk;
+#pragma unroll
+          for (int jj = 0; jj < R; ++jj) tap_load(tb[jj], pb, hb[jj]);
+          smp_load(vb, xa + 32u);
+          pb += kShChunk;
+          xa += 64u;
+          asm volatile("" : "+v"(va[0]));
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+#pragma unroll
+            for (int jj = 0; jj < R; ++jj) acc[jj] = acc[jj] + va[u >> 1][u & 1] * ta[jj][u];
+          }
+          tap_wait(tb, vb);
+          // past the last chunk these fetch margin zeros and the samples behind the window; unused
+#pragma unroll
+          for (int jj = 0; jj < R; ++jj) tap_load(ta[jj], pa, hb[jj]);
+          smp_load(va, xa);
+          asm volatile("" : "+v"(vb[0]));
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+#pragma unroll
+            for (int jj = 0; jj < R; ++jj) acc[jj] = acc[jj] + vb[u >> 1][u & 1] * tb[jj][u];
+          }
+        }
+        tap_wait(ta, va);  // nothing may stay in flight into registers the compiler reuses
+        float* __restrict__ ol = orow + lane * U + jb * R;
+        if (r.cnt == run && jb * R + R <= U) {  // wave-uniform: a whole run, a whole step
+#pragma unroll
+          for (int jj = 0; jj < R; ++jj) ol[jj] = acc[jj];
+        } else {
+#pragma unroll
+          for (int jj = 0; jj < R; ++jj) {
+            const int j = jb * R + jj;
+            if (j < U && lane * U + j < r.cnt) ol[jj] = acc[jj];
+          }
+        }
+      }
+    } else {
+      for (int w = tid; w < r.cnt; w += nthr) {
+        const unsigned q = r.ph0 + (unsigned)w * (unsigned)down;
+        const unsigned xi = q / (unsigned)up;
+        const unsigned t = q - xi * (unsigned)up;
+        const float* __restrict__ hh = table + (size_t)t * PP + margin;
+        const float* xk = xs + shift + xi;
+        float acc = 0.0f;
+        for (int j = 0; j < P; ++j) acc = acc + xk[j] * hh[j];
+        orow[w] = acc;
+      }
+    }
+    __syncthreads();  // the next run overwrites the staged samples
+  }
+}
+
+// Launch shape of the shared-window kernel for one (up, down, taps-per-phase), or false when
+// it does not apply: lanes c * down samples apart must not meet in one LDS bank more than
+// two at a time, and 64 sub-runs' samples must fit the workgroup's LDS.
+struct ShPlan {
+  int c, U, cd, R, span_cap, margin, threads;
+};
+
+static bool sh_plan(int up, int down, int P, ShPlan* pl) {
+  if (up < 1 || down < 1 || P < 1) return false;
+  const long long dmax5 = ((long long)up - 1 + 4LL * down) / up;  // for the most outputs per step
+  if (dmax5 > 2048) return false;
+  const long long extra5 = (long long)P + dmax5 + 40 + 4;
+  const long long caps[2] = {19000, 38000};  // floats of LDS: two workgroups per CU, else one
+  for (int ci = 0; ci < 2; ++ci) {
+    const long long cmax = (caps[ci] - extra5) / (64LL * down);
+    if (cmax < 1) continue;
+    long long best_c = 0;
+    double best = 1e9;
+    for (long long c = cmax; c >= 1 && c > cmax - 32; --c) {
+      const long long cd = c * down, U = c * up;
+      if (cd % 4 == 0) continue;
+      if ((64 * U + 8) * (long long)down + up >= 0x7fffffffLL) continue;
+      const double score = (cd % 2 == 0 ? 0.5 : 0.0) + 0.001 * double(cmax - c);
+      if (score < best) {
+        best = score;
+        best_c = c;
+      }
+    }
+    if (best_c == 0) continue;
+    const long long U = best_c * up;
+    if (U < 32 && ci == 0) continue;  // few outputs per sub-run: try the larger span
+    if (U < 8) return false;
+    // outputs per lane and wave-step (two sets of 8 taps each have to fit the scalar registers):
+    // the one with the least work on the busiest wave (steps per wave x chunks per step x
+    // outputs per step, zero-tap positions included)
+    int best_r = 0;
+    long long best_work = 0;
+    for (int r = 5; r >= 4; --r) {
+      const long long nblocks = (U + r - 1) / r;
+      const long long nw = nblocks < 16 ? nblocks : 16;
+      const long long d = ((long long)up - 1 + (long long)(r - 1) * down) / up;
+      const long long work = ((nblocks + nw - 1) / nw) * ((P + d + kShChunk - 1) / kShChunk) * r;
+      if (best_r == 0 || work < best_work) {
+        best_r = r;
+        best_work = work;
+      }
+    }
+    const long long dmax = ((long long)up - 1 + (long long)(best_r - 1) * down) / up;
+    pl->c = (int)best_c;
+    pl->U = (int)U;
+    pl->cd = (int)(best_c * down);
+    pl->R = best_r;
+    pl->span_cap = (int)((64LL * pl->cd + P + dmax + 40 + 4 + 3) & ~3LL);
+    pl->margin = (int)dmax + 24;
+    const long long nblocks = (U + best_r - 1) / best_r;
+    pl->threads = (int)(64 * (nblocks < 16 ? nblocks : 16));
+    return true;
+  }
+  return false;
+}
+
 __global__ __launch_bounds__(256) void lerp_kernel(const float* __restrict__ x, long long rows,
                                                    long long n_in, long long n_out, double step,
                                                    double gain, float* __restrict__ out) {
@@ -294,6 +626,70 @@ int mia_upfirdn(const float* x, int64_t rows, int64_t n_in, const float* phase_t
                        phase_table, up, down, P, (long long)skip, (long long)n_out, pad_mode, out,
                        (int)S, kcount, span_cap, runs_per_row, total_runs, runs_per_wg);
   }
+  MIA_CHECK_HIP(hipGetLastError());
+  return MIA_OK;
+}
+
+int mia_upfirdn_margin(int up, int down, int taps_per_phase, int64_t n_out) {
+  mia::ShPlan pl;
+  if (!mia::sh_plan(up, down, taps_per_phase, &pl)) return 0;
+  if (n_out < 64LL * pl.U) return 0;  // not one full run per row: the per-output kernel
+  return pl.margin;
+}
+
+int mia_upfirdn_shared(const float* x, int64_t rows, int64_t n_in, const float* padded_table,
+                       int margin, int up, int down, int taps_per_phase, int64_t skip,
+                       int64_t n_out, int pad_mode, float* out, void* stream) {
+  using namespace mia;
+  MIA_REQUIRE(rows >= 0 && n_in >= 1 && n_out >= 0, "rows, n_in, n_out must be >= 0, 1, 0");
+  MIA_REQUIRE(up >= 1 && down >= 1 && taps_per_phase >= 1 && skip >= 0,
+              "up, down, taps_per_phase must be >= 1 and skip >= 0");
+  MIA_REQUIRE(pad_mode >= MIA_RS_PAD_CONSTANT && pad_mode <= MIA_RS_PAD_WRAP,
+              "unknown padding mode %d", pad_mode);
+  ShPlan pl;
+  if (!sh_plan(up, down, taps_per_phase, &pl)) {
+    set_error("no shared-window plan for up %d, down %d, %d taps per phase (use mia_upfirdn)", up,
+              down, taps_per_phase);
+    return MIA_ERR_UNSUPPORTED;
+  }
+  MIA_REQUIRE(margin == pl.margin, "table margin is %d, mia_upfirdn_margin says %d", margin,
+              pl.margin);
+  if (rows == 0 || n_out == 0) return MIA_OK;
+  MIA_REQUIRE(x && padded_table && out, "null pointer");
+  if ((long long)(skip + n_out) > (0x7fffffffffffffffLL / down)) {
+    set_error("resample: row of %lld outputs is too long", (long long)n_out);
+    return MIA_ERR_UNSUPPORTED;
+  }
+  const long long run = 64LL * pl.U;
+  const long long runs_per_row = (n_out + run - 1) / run;
+  const long long total_runs = rows * runs_per_row;
+  const size_t lds = sizeof(float) * ((size_t)pl.span_cap + (size_t)kShBt * ((pl.U + pl.R - 1) / pl.R)) + 16;
+  int dev = 0, cus = 256;
+  MIA_CHECK_HIP(hipGetDevice(&dev));
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  long long per_cu = (160 * 1024) / (long long)(lds + 256);
+  if (per_cu > 2048 / pl.threads) per_cu = 2048 / pl.threads;
+  if (per_cu > 4) per_cu = 4;
+  if (per_cu < 1) per_cu = 1;
+  long long grid = (long long)cus * per_cu;
+  if (grid > total_runs) grid = total_runs;
+  const long long per_wg = (total_runs + grid - 1) / grid;
+  if (per_wg > 0x7fffffffLL) {
+    set_error("resample: %lld output runs do not fit one launch (split the batch)", total_runs);
+    return MIA_ERR_UNSUPPORTED;
+  }
+  grid = (total_runs + per_wg - 1) / per_wg;
+  void (*kern)(const float*, long long, const float*, int, int, int, int, long long, long long, int,
+               float*, int, int, int, long long, long long, int) = nullptr;
+  kern = pl.R == 4 ? upfirdn_shared_kernel<4> : upfirdn_shared_kernel<5>;
+  if (lds > 64 * 1024) {
+    MIA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(pl.threads), lds, (hipStream_t)stream, x,
+                     (long long)n_in, padded_table, up, down, taps_per_phase, pl.margin,
+                     (long long)skip, (long long)n_out, pad_mode, out, pl.U, pl.cd, pl.span_cap,
+                     runs_per_row, total_runs, (int)per_wg);
   MIA_CHECK_HIP(hipGetLastError());
   return MIA_OK;
 }

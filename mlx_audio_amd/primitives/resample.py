@@ -202,14 +202,18 @@ def _phase_table(h: np.ndarray, pre: int, post: int, up: int) -> np.ndarray:
 _table_dev_cache: dict = {}
 
 
-def _phase_table_dev(up: int, down: int, pre: int, post: int, device) -> torch.Tensor:
-    key = (up, down, pre, post, device.index)
+def _phase_table_dev(up: int, down: int, pre: int, post: int, device, margin: int = 0) -> torch.Tensor:
+    """The phase table on the device; with `margin`, every row between that many zeros."""
+    key = (up, down, pre, post, device.index, margin)
     t = _table_dev_cache.get(key)
     if t is None:
         if len(_table_dev_cache) >= 64:
             _table_dev_cache.clear()
         h, _ = _kaiser_lowpass(up, down)
-        t = torch.from_numpy(_phase_table(h, pre, post, up)).to(device)
+        table = _phase_table(h, pre, post, up)
+        if margin:
+            table = np.pad(table, ((0, 0), (margin, margin)))
+        t = torch.from_numpy(np.ascontiguousarray(table)).to(device)
         _table_dev_cache[key] = t
     return t
 
@@ -242,7 +246,11 @@ def resample_poly(y, up: int, down: int, axis: int = -1, padtype: str = "constan
         raise ValueError("cannot resample an empty signal")
     h, half_len = _kaiser_lowpass(up, down)
     pre, post, skip, n_out = _poly_layout(n_in, up, down, half_len, len(h))
-    table = _phase_table_dev(up, down, pre, post, x.device)
+    taps_per_phase = -(-(pre + len(h) + post) // up)
+    # 0: the per-output kernel; else the kernel that shares sample windows between adjacent
+    # outputs, which wants its table rows between that many zeros
+    margin = _lib.lib().mia_upfirdn_margin(up, down, taps_per_phase, n_out)
+    table = _phase_table_dev(up, down, pre, post, x.device, margin)
 
     background = None
     mode = _lib.RS_PAD_MODES.get(padtype, 0)
@@ -260,9 +268,14 @@ def resample_poly(y, up: int, down: int, axis: int = -1, padtype: str = "constan
 
     out = torch.empty((rows, n_out), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
-        _lib.check(_lib.lib().mia_upfirdn(
-            x.data_ptr(), rows, n_in, table.data_ptr(), up, down, table.shape[1], skip, n_out,
-            mode, out.data_ptr(), stream_ptr(x.device)))
+        if margin:
+            _lib.check(_lib.lib().mia_upfirdn_shared(
+                x.data_ptr(), rows, n_in, table.data_ptr(), margin, up, down, taps_per_phase,
+                skip, n_out, mode, out.data_ptr(), stream_ptr(x.device)))
+        else:
+            _lib.check(_lib.lib().mia_upfirdn(
+                x.data_ptr(), rows, n_in, table.data_ptr(), up, down, taps_per_phase, skip,
+                n_out, mode, out.data_ptr(), stream_ptr(x.device)))
     if background is not None:
         out += background
     return _restore(out, is_1d, axis)

@@ -82,6 +82,82 @@ def test_resample_poly_nonfinite_samples_stay_local(gpu):
     assert np.isfinite(got[0, :300]).all()
 
 
+SHARED_RATIOS = [(160, 441), (1, 3), (3, 1), (1, 2), (2, 1), (160, 147), (2, 3),
+                 (1, 6), (5, 7)]
+
+
+def _taps_per_phase(n_in, up, down):
+    from mlx_audio_amd.primitives.resample import _kaiser_lowpass, _poly_layout
+    h, half_len = _kaiser_lowpass(up, down)
+    pre, post, skip, n_out = _poly_layout(n_in, up, down, half_len, len(h))
+    return -(-(pre + len(h) + post) // up), n_out
+
+
+@pytest.mark.parametrize("up,down", SHARED_RATIOS)
+def test_shared_window_kernel_is_bit_identical_to_scipy(gpu, up, down):
+    """Rows long enough for the kernel that shares a lane's sample window between adjacent
+    outputs (several runs per row, a ragged last run, rows at every 4-byte phase of a 16-byte
+    line), against SciPy bit for bit, with zero and with signal extension at the ends."""
+    rng = np.random.default_rng(7 * up + down)
+    n = 100003 if down >= up else 60001
+    P, n_out = _taps_per_phase(n, up, down)
+    assert _lib.lib().mia_upfirdn_margin(up, down, P, n_out) > 0   # the path under test
+    x = rng.standard_normal((5, n)).astype(np.float32)
+    for padtype in ("constant", "reflect", "wrap"):
+        want = orc.resample_poly(x, up, down, padtype=padtype)
+        got = resample_poly(_dev(x, gpu), up, down, padtype=padtype).cpu().numpy()
+        np.testing.assert_array_equal(got, want, err_msg=f"{up}/{down} {padtype}")
+
+
+def test_shared_window_kernel_with_nonfinite_samples(gpu):
+    """A product of an infinite sample with a zero tap is NaN, not zero: runs that hold a
+    non-finite sample must give exactly what the per-output sum gives (the other runs too)."""
+    rng = np.random.default_rng(21)
+    x = rng.standard_normal((3, 120000)).astype(np.float32)
+    x[0, 50000] = np.inf
+    x[1, 119990] = np.nan
+    x[1, 3] = -np.inf
+    for up, down in ((160, 441), (1, 3), (3, 1)):
+        want = orc.resample_poly(x, up, down)
+        got = resample_poly(_dev(x, gpu), up, down).cpu().numpy()
+        np.testing.assert_array_equal(got, want, err_msg=f"{up}/{down}")
+        assert np.isfinite(got[2]).all() and np.isfinite(got[0, :1000]).all()
+
+
+def test_shared_window_and_per_output_kernels_agree_through_the_c_abi(gpu):
+    from mlx_audio_amd.primitives.resample import (_kaiser_lowpass, _phase_table_dev,
+                                                     _poly_layout)
+    lib = _lib.lib()
+    up, down, rows = 160, 441, 4
+    g = torch.Generator(device=gpu)
+    g.manual_seed(3)
+    for n_in in (44100 * 3, 44100 * 3 + 1):   # odd row length: rows start at every 4-byte phase
+        x = torch.randn((rows, n_in), generator=g, device=gpu, dtype=torch.float32)
+        h, half_len = _kaiser_lowpass(up, down)
+        pre, post, skip, n_out = _poly_layout(n_in, up, down, half_len, len(h))
+        P = -(-(pre + len(h) + post) // up)
+        margin = lib.mia_upfirdn_margin(up, down, P, n_out)
+        assert margin > 0
+        plain = _phase_table_dev(up, down, pre, post, x.device)
+        padded = _phase_table_dev(up, down, pre, post, x.device, margin)
+        assert padded.shape == (up, P + 2 * margin)
+        a = torch.empty((rows, n_out), device=gpu)
+        b = torch.full((rows, n_out), 7.0, device=gpu)
+        stream = torch.cuda.current_stream(gpu).cuda_stream
+        _lib.check(lib.mia_upfirdn(x.data_ptr(), rows, n_in, plain.data_ptr(), up, down, P, skip,
+                                   n_out, 0, a.data_ptr(), stream))
+        _lib.check(lib.mia_upfirdn_shared(x.data_ptr(), rows, n_in, padded.data_ptr(), margin, up,
+                                          down, P, skip, n_out, 0, b.data_ptr(), stream))
+        assert torch.equal(a, b)
+    # a table with another margin, and a ratio the kernel does not take, are refused
+    assert lib.mia_upfirdn_shared(x.data_ptr(), rows, n_in, padded.data_ptr(), margin + 1, up, down,
+                                  P, skip, n_out, 0, b.data_ptr(), stream) == _lib.MIA_ERR_INVALID
+    assert lib.mia_upfirdn_margin(147, 160, 22, 10 ** 6) == 0
+    assert lib.mia_upfirdn_shared(x.data_ptr(), rows, n_in, padded.data_ptr(), 20, 147, 160, 22,
+                                  skip, n_out, 0, b.data_ptr(), stream) == _lib.MIA_ERR_UNSUPPORTED
+    assert lib.mia_upfirdn_margin(up, down, P, 1000) == 0    # short rows: the per-output kernel
+
+
 @pytest.mark.parametrize("orig,target", [(44100, 16000), (16000, 44100), (48000, 16000),
                                          (22050, 16000), (8000, 48000), (16000, 15999)])
 def test_linear_is_bit_identical_to_numpy(gpu, orig, target):
