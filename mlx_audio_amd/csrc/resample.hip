@@ -192,29 +192,39 @@ constexpr int kShChunk = 16;  // samples per chunk of a wave-step (two half-chun
 constexpr int kShPre = 8;    // 16-byte loads per thread that hold the next run's span
 constexpr int kShBt = 12;    // ints per wave-step in the table of step constants
 
-struct ShRun {
-  long long row, o0, x_first;
-  unsigned ph0;
-  int cnt, span, lead, quads;
+// Where run k of a row lies.  A run is 64 U outputs = a whole number of filter periods, so run k
+// starts 64 c * down samples after run 0 and on the same phase: no division per run (every
+// wave works this out for itself, on the scalar unit: two 64-bit divisions per run and wave
+// were a quarter of all instructions the kernel issued).
+struct ShGeom {
+  long long xq_skip;  // sample index of output 0's newest sample: (skip * down) / up
+  unsigned ph0;       // and its phase: (skip * down) % up
+  int span_full;      // samples a full run stages
+  int run, stride, P, over, up, down;
 };
 
-__device__ __forceinline__ ShRun sh_run(long long item, long long runs_per_row, int run,
-                                        long long n_out, long long skip, int up, int down, int P,
-                                        int over, const float* __restrict__ x, long long n_in) {
+struct ShRun {
+  long long row, o0, x_first;
+  int k, cnt, span, lead, quads;
+};
+
+__device__ __forceinline__ ShRun sh_run(const ShGeom& g, long long row, int k, long long n_out,
+                                        const float* __restrict__ x, long long n_in) {
   ShRun r;
-  r.row = item / runs_per_row;
-  r.o0 = (item - r.row * runs_per_row) * run;
+  r.row = row;
+  r.k = k;
+  r.o0 = (long long)k * g.run;
   const long long rem = n_out - r.o0;
-  r.cnt = rem < run ? (int)rem : run;
-  const long long q0 = (r.o0 + skip) * down;
-  const long long xq0 = q0 / up;
-  r.ph0 = (unsigned)(q0 - xq0 * up);
-  r.x_first = xq0 - P + 1;
-  const unsigned q_last = r.ph0 + (unsigned)(r.cnt - 1) * (unsigned)down;
+  r.cnt = rem < g.run ? (int)rem : g.run;
+  r.x_first = (long long)k * g.stride + g.xq_skip - g.P + 1;
   // `over` samples behind the last window are read too (with zero taps): they must be staged,
   // so that they are finite or seen not to be
-  r.span = (int)(q_last / (unsigned)up) + P + over;
-  const float* xr = x + r.row * n_in;
+  r.span = g.span_full;
+  if (r.cnt != g.run) {
+    const unsigned q_last = g.ph0 + (unsigned)(r.cnt - 1) * (unsigned)g.down;
+    r.span = (int)(q_last / (unsigned)g.up) + g.P + g.over;
+  }
+  const float* xr = x + row * n_in;
   r.lead = (int)(((uintptr_t)(xr + r.x_first) >> 2) & 3);
   r.quads = (r.span + r.lead + 3) >> 2;
   return r;
@@ -306,13 +316,23 @@ __global__ __launch_bounds__(1024) void upfirdn_shared_kernel(
 
   const long long first = (long long)blockIdx.x * runs_per_wg;
   const long long last = first + runs_per_wg < total_runs ? first + runs_per_wg : total_runs;
+  ShGeom g;
+  {
+    const long long qs = skip * down;
+    g.xq_skip = qs / up;
+    g.ph0 = (unsigned)(qs - g.xq_skip * up);
+    g.run = run, g.stride = 64 * cd, g.P = P, g.over = margin, g.up = up, g.down = down;
+    g.span_full = (int)((g.ph0 + (unsigned)(run - 1) * (unsigned)down) / (unsigned)up) + P + margin;
+  }
+  long long row = first / runs_per_row;
+  int k = (int)(first - row * runs_per_row);
+  ShRun r = sh_run(g, row, k, n_out, x, n_in);
   float4 pre[kShPre];
 #pragma unroll
   for (int k = 0; k < kShPre; ++k) pre[k] = make_float4(0.f, 0.f, 0.f, 0.f);
   bool have_pre = false;
   for (long long item = first; item < last; ++item) {
     const int id = (int)(item - first);
-    const ShRun r = sh_run(item, runs_per_row, run, n_out, skip, up, down, P, margin, x, n_in);
     const float* __restrict__ xr = x + r.row * n_in;
 
     // the run's span of samples into LDS, 16 bytes at a time from a 16-byte boundary of the
@@ -344,8 +364,13 @@ __global__ __launch_bounds__(1024) void upfirdn_shared_kernel(
     const bool plain = __builtin_amdgcn_readfirstlane(*flag) == id;
 
     have_pre = false;
+    ShRun nx = r;
     if (item + 1 < last) {
-      const ShRun nx = sh_run(item + 1, runs_per_row, run, n_out, skip, up, down, P, margin, x, n_in);
+      if (++k == (int)runs_per_row) {
+        k = 0;
+        ++row;
+      }
+      nx = sh_run(g, row, k, n_out, x, n_in);
       if (nx.quads <= kShPre * nthr) {
         const float* __restrict__ nr = x + nx.row * n_in;
 #pragma unroll
@@ -427,7 +452,7 @@ __global__ __launch_bounds__(1024) void upfirdn_shared_kernel(
       }
     } else {
       for (int w = tid; w < r.cnt; w += nthr) {
-        const unsigned q = r.ph0 + (unsigned)w * (unsigned)down;
+        const unsigned q = g.ph0 + (unsigned)w * (unsigned)down;
         const unsigned xi = q / (unsigned)up;
         const unsigned t = q - xi * (unsigned)up;
         const float* __restrict__ hh = table + (size_t)t * PP + margin;
@@ -438,6 +463,7 @@ __global__ __launch_bounds__(1024) void upfirdn_shared_kernel(
       }
     }
     __syncthreads();  // the next run overwrites the staged samples
+    r = nx;
   }
 }
 
@@ -674,7 +700,7 @@ int mia_upfirdn_shared(const float* x, int64_t rows, int64_t n_in, const float* 
   long long grid = (long long)cus * per_cu;
   if (grid > total_runs) grid = total_runs;
   const long long per_wg = (total_runs + grid - 1) / grid;
-  if (per_wg > 0x7fffffffLL) {
+  if (per_wg > 0x7fffffffLL || runs_per_row > 0x7fffffffLL) {
     set_error("resample: %lld output runs do not fit one launch (split the batch)", total_runs);
     return MIA_ERR_UNSUPPORTED;
   }
