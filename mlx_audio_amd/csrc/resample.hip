@@ -259,15 +259,6 @@ __device__ __forceinline__ bool not_finite4(const float4 v) {
            __builtin_isfinite(v.w));
 }
 
-// Samples a .. a+3 of the row (a is a multiple of four samples from a 16-byte boundary): one
-// 16-byte load when they lie inside the row, else sample by sample with the signal extension.
-__device__ __forceinline__ float4 sh_quad(const float* __restrict__ xr, long long n_in, long long a,
-                                          int mode) {
-  if (a >= 0 && a + 4 <= n_in) return *reinterpret_cast<const float4*>(xr + a);
-  return make_float4(extended_sample(xr, n_in, a, mode), extended_sample(xr, n_in, a + 1, mode),
-                     extended_sample(xr, n_in, a + 2, mode), extended_sample(xr, n_in, a + 3, mode));
-}
-
 template <int R>
 __global__ __launch_bounds__(1024) void upfirdn_shared_kernel(
     const float* __restrict__ x, long long n_in, const float* __restrict__ table, int up, int down,
@@ -288,7 +279,7 @@ __global__ __launch_bounds__(1024) void upfirdn_shared_kernel(
   // phases and sample offsets of a wave-step's R outputs are the same in every run: worked out
   // once.  Entry jj < R: byte offset into the table of the taps that go with the step's sample
   // position 0 for output jj (row * pitch + margin - d_jj); entry 8: the step's first sample,
-  // relative to the lane's; entry 9: its number of chunks.
+  // relative to the lane's; entry 9: its number of half-chunks.
   {
     const unsigned ph0 = (unsigned)((skip * down) % up);
     const unsigned ddiv = (unsigned)down / (unsigned)up, dmod = (unsigned)down % (unsigned)up;
@@ -309,7 +300,7 @@ __global__ __launch_bounds__(1024) void upfirdn_shared_kernel(
         }
       }
       bt[jb * kShBt + 8] = (int)xi0;
-      bt[jb * kShBt + 9] = (P + dlast + kShChunk - 1) / kShChunk;
+      bt[jb * kShBt + 9] = (P + dlast + kShChunk / 2 - 1) / (kShChunk / 2);
     }
   }
   __syncthreads();
@@ -337,25 +328,43 @@ __global__ __launch_bounds__(1024) void upfirdn_shared_kernel(
 
     // the run's span of samples into LDS, 16 bytes at a time from a 16-byte boundary of the
     // row (`lead` samples early): from the registers filled during the previous run, else
-    // fetched here; a thread that meets a non-finite sample marks the run
+    // fetched here; quads that leave the row are built sample by sample with the signal
+    // extension; a thread that meets a non-finite sample marks the run
     bool bad = false;
     const int shift = r.lead;
     {
       float4* dst = reinterpret_cast<float4*>(xs);
+      const long long a0 = r.x_first - r.lead;  // sample index of quad 0 (may lie before the row)
       if (have_pre) {
 #pragma unroll
-        for (int k = 0; k < kShPre; ++k) {
-          const int i = tid + k * nthr;
-          if (i < r.quads) {
-            dst[i] = pre[k];
-            bad |= not_finite4(pre[k]);
+        for (int kk = 0; kk < kShPre; ++kk) {
+          const int i = tid + kk * nthr;
+          const long long a = a0 + 4LL * i;
+          if (i < r.quads && a >= 0 && a + 4 <= n_in) {
+            dst[i] = pre[kk];
+            bad |= not_finite4(pre[kk]);
           }
         }
       } else {
         for (int i = tid; i < r.quads; i += nthr) {
-          const float4 v = sh_quad(xr, n_in, r.x_first - r.lead + 4LL * i, mode);
-          dst[i] = v;
-          bad |= not_finite4(v);
+          const long long a = a0 + 4LL * i;
+          if (a >= 0 && a + 4 <= n_in) {
+            const float4 v = *reinterpret_cast<const float4*>(xr + a);
+            dst[i] = v;
+            bad |= not_finite4(v);
+          }
+        }
+      }
+      if (a0 < 0 || a0 + 4LL * r.quads > n_in) {  // the run touches an end of the row (wave-uniform)
+        for (int i = tid; i < r.quads; i += nthr) {
+          const long long a = a0 + 4LL * i;
+          if (a >= 0 && a + 4 <= n_in) continue;
+#pragma unroll 1
+          for (int e = 0; e < 4; ++e) {
+            const float v = extended_sample(xr, n_in, a + e, mode);
+            xs[4 * i + e] = v;
+            bad |= !__builtin_isfinite(v);
+          }
         }
       }
     }
@@ -373,10 +382,13 @@ __global__ __launch_bounds__(1024) void upfirdn_shared_kernel(
       nx = sh_run(g, row, k, n_out, x, n_in);
       if (nx.quads <= kShPre * nthr) {
         const float* __restrict__ nr = x + nx.row * n_in;
+        const long long a0 = nx.x_first - nx.lead;
 #pragma unroll
-        for (int k = 0; k < kShPre; ++k) {
-          const int i = tid + k * nthr;
-          if (i < nx.quads) pre[k] = sh_quad(nr, n_in, nx.x_first - nx.lead + 4LL * i, mode);
+        for (int kk = 0; kk < kShPre; ++kk) {
+          const int i = tid + kk * nthr;
+          const long long a = a0 + 4LL * i;  // quads that leave the row are filled when staged
+          if (i < nx.quads && a >= 0 && a + 4 <= n_in)
+            pre[kk] = *reinterpret_cast<const float4*>(nr + a);
         }
         have_pre = true;
       }
@@ -411,7 +423,7 @@ __global__ __launch_bounds__(1024) void upfirdn_shared_kernel(
 #pragma unroll
         for (int jj = 0; jj < R; ++jj) tap_load(ta[jj], pa, hb[jj]);
         smp_load(va, xa);
-        for (int c = 0; c < nch; ++c) {
+        for (int c = 0; 2 * c < nch; ++c) {  // nch counts half-chunks
           tap_wait(ta, va);
           pa += kShChunk;
 #pragma unroll
@@ -426,15 +438,17 @@ __global__ __launch_bounds__(1024) void upfirdn_shared_kernel(
             for (int jj = 0; jj < R; ++jj) acc[jj] = acc[jj] + va[u >> 1][u & 1] * ta[jj][u];
           }
           tap_wait(tb, vb);
-          // past the last chunk these fetch margin zeros and the samples behind the window; unused
+          // behind the last half-chunk these fetch margin zeros and the samples behind the window; unused
 #pragma unroll
           for (int jj = 0; jj < R; ++jj) tap_load(ta[jj], pa, hb[jj]);
           smp_load(va, xa);
           asm volatile("" : "+v"(vb[0]));
+          if (2 * c + 1 < nch) {  // an odd count ends behind the first half (all taps zero beyond)
 #pragma unroll
-          for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < 8; ++u) {
 #pragma unroll
-            for (int jj = 0; jj < R; ++jj) acc[jj] = acc[jj] + vb[u >> 1][u & 1] * tb[jj][u];
+              for (int jj = 0; jj < R; ++jj) acc[jj] = acc[jj] + vb[u >> 1][u & 1] * tb[jj][u];
+            }
           }
         }
         tap_wait(ta, va);  // nothing may stay in flight into registers the compiler reuses
