@@ -154,3 +154,21 @@ def test_compiled_whisper_banks_are_current_and_bit_exact():
         got = gen.filterbank(n_mels)
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
     assert gen.generate() == open(gen.OUT).read()
+
+
+def test_upfirdn_margin_is_host_only_and_says_where_the_shared_window_kernel_applies():
+    """mia_upfirdn_margin touches no device: zeros for rows shorter than one run of outputs and
+    for lane spacings that would meet in one LDS bank (down a multiple of 4), else the number of
+    zeros mia_upfirdn_shared wants on both sides of every phase-table row; it grows with
+    down / up (the offset between the windows of adjacent outputs)."""
+    lib = _lib.lib()
+    long_row = 10 ** 7
+    assert lib.mia_upfirdn_margin(160, 441, 56, 1000) == 0
+    assert lib.mia_upfirdn_margin(147, 160, 22, long_row) == 0
+    assert lib.mia_upfirdn_margin(441, 160, 21, long_row) == 0
+    assert lib.mia_upfirdn_margin(1, 4, 81, long_row) == 0
+    assert lib.mia_upfirdn_margin(0, 3, 61, long_row) == 0      # not a ratio
+    margins = [lib.mia_upfirdn_margin(1, d, 20 * d + 1, long_row) for d in (1, 2, 3, 5, 6, 7)]
+    assert all(m > 0 for m in margins) and margins == sorted(margins)
+    for up, down, taps in ((160, 441, 56), (3, 1, 21), (2, 1, 21), (160, 147, 21), (320, 441, 28)):
+        assert lib.mia_upfirdn_margin(up, down, taps, long_row) > 0, (up, down)
