@@ -12,7 +12,10 @@
 // of input samples the run touches in LDS with coalesced loads (signal extension folded
 // in), keeps the phase table in LDS too when it fits, and every thread then walks its
 // outputs with independent accumulators.  HBM sees each input sample about once per
-// workgroup that touches it and each output once.
+// workgroup that touches it and each output once.  (upfirdn_kernel: any ratio, any row length.)
+// A second kernel, upfirdn_shared_kernel further down, gives the same bits faster for the ratios
+// and row lengths it takes: lanes a whole number of filter periods apart, taps through the scalar
+// cache, the samples of adjacent outputs read from LDS once.
 #include "mia_internal.h"
 
 // Products and sums in this file are rounded one by one, as the host code they stand in
