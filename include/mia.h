@@ -263,8 +263,9 @@ int mia_upfirdn(const float* x, int64_t rows, int64_t n_in, const float* phase_t
  * between adjacent outputs: same arguments and the same bits out, but the phase table's
  * rows carry `margin` zeros in front of and behind their taps_per_phase taps — device
  * (up, margin + taps_per_phase + margin).  mia_upfirdn_margin returns the margin this kernel
- * needs for the ratio, or 0 when it does not apply (lane spacing that meets in one LDS bank,
- * spans beyond the LDS, rows shorter than one run of outputs): then call mia_upfirdn. */
+ * needs for the ratio, or 0 when it does not apply (spans beyond the LDS, short filters whose
+ * lanes would meet in one LDS bank, rows shorter than one run of outputs): then call
+ * mia_upfirdn. */
 int mia_upfirdn_margin(int up, int down, int taps_per_phase, int64_t n_out);
 int mia_upfirdn_shared(const float* x, int64_t rows, int64_t n_in, const float* padded_table,
                        int margin, int up, int down, int taps_per_phase, int64_t skip,

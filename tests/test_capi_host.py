@@ -157,18 +157,19 @@ def test_compiled_whisper_banks_are_current_and_bit_exact():
 
 
 def test_upfirdn_margin_is_host_only_and_says_where_the_shared_window_kernel_applies():
-    """mia_upfirdn_margin touches no device: zeros for rows shorter than one run of outputs and
-    for lane spacings that would meet in one LDS bank (down a multiple of 4), else the number of
-    zeros mia_upfirdn_shared wants on both sides of every phase-table row; it grows with
-    down / up (the offset between the windows of adjacent outputs)."""
+    """mia_upfirdn_margin touches no device: zero for rows shorter than one run of outputs and
+    for ratios whose lanes' samples do not fit the LDS, else the number of zeros
+    mia_upfirdn_shared wants on both sides of every phase-table row; it grows with down / up
+    (the offset between the windows of adjacent outputs)."""
     lib = _lib.lib()
     long_row = 10 ** 7
     assert lib.mia_upfirdn_margin(160, 441, 56, 1000) == 0
-    assert lib.mia_upfirdn_margin(147, 160, 22, long_row) == 0
-    assert lib.mia_upfirdn_margin(441, 160, 21, long_row) == 0
-    assert lib.mia_upfirdn_margin(1, 4, 81, long_row) == 0
+    assert lib.mia_upfirdn_margin(1, 8, 161, long_row) == 0     # rows too long for a lane each
+    assert lib.mia_upfirdn_margin(147, 160, 22, long_row) == 0  # lanes a multiple of 4 samples
+    assert lib.mia_upfirdn_margin(441, 160, 21, long_row) == 0  # apart and a short filter
     assert lib.mia_upfirdn_margin(0, 3, 61, long_row) == 0      # not a ratio
     margins = [lib.mia_upfirdn_margin(1, d, 20 * d + 1, long_row) for d in (1, 2, 3, 5, 6, 7)]
     assert all(m > 0 for m in margins) and margins == sorted(margins)
-    for up, down, taps in ((160, 441, 56), (3, 1, 21), (2, 1, 21), (160, 147, 21), (320, 441, 28)):
+    for up, down, taps in ((160, 441, 56), (3, 1, 21), (2, 1, 21), (160, 147, 21), (320, 441, 28),
+                           (1, 4, 81), (3, 8, 55)):
         assert lib.mia_upfirdn_margin(up, down, taps, long_row) > 0, (up, down)

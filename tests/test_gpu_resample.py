@@ -83,7 +83,10 @@ def test_resample_poly_nonfinite_samples_stay_local(gpu):
 
 
 SHARED_RATIOS = [(160, 441), (1, 3), (3, 1), (1, 2), (2, 1), (160, 147), (2, 3),
-                 (1, 6), (5, 7)]
+                 (1, 6), (5, 7),
+                 # lane spacings that are a multiple of four samples: the row-per-lane layout
+                 # (long filters only: 48 -> 44.1 kHz stays on the per-output kernel)
+                 (1, 4), (3, 8)]
 
 
 def _taps_per_phase(n_in, up, down):
@@ -117,7 +120,7 @@ def test_shared_window_kernel_with_nonfinite_samples(gpu):
     x[0, 50000] = np.inf
     x[1, 119990] = np.nan
     x[1, 3] = -np.inf
-    for up, down in ((160, 441), (1, 3), (3, 1)):
+    for up, down in ((160, 441), (1, 3), (3, 1), (1, 4)):
         want = orc.resample_poly(x, up, down)
         got = resample_poly(_dev(x, gpu), up, down).cpu().numpy()
         np.testing.assert_array_equal(got, want, err_msg=f"{up}/{down}")
@@ -152,8 +155,8 @@ def test_shared_window_and_per_output_kernels_agree_through_the_c_abi(gpu):
     # a table with another margin, and a ratio the kernel does not take, are refused
     assert lib.mia_upfirdn_shared(x.data_ptr(), rows, n_in, padded.data_ptr(), margin + 1, up, down,
                                   P, skip, n_out, 0, b.data_ptr(), stream) == _lib.MIA_ERR_INVALID
-    assert lib.mia_upfirdn_margin(147, 160, 22, 10 ** 6) == 0
-    assert lib.mia_upfirdn_shared(x.data_ptr(), rows, n_in, padded.data_ptr(), 20, 147, 160, 22,
+    assert lib.mia_upfirdn_margin(1, 8, 161, 10 ** 6) == 0
+    assert lib.mia_upfirdn_shared(x.data_ptr(), rows, n_in, padded.data_ptr(), 20, 1, 8, 161,
                                   skip, n_out, 0, b.data_ptr(), stream) == _lib.MIA_ERR_UNSUPPORTED
     assert lib.mia_upfirdn_margin(up, down, P, 1000) == 0    # short rows: the per-output kernel
 

@@ -6,7 +6,8 @@ from mlx_audio_amd import _lib
 from mlx_audio_amd.primitives.resample import _kaiser_lowpass, _phase_table_dev, _poly_layout
 
 CASES = [(44100, 16000), (48000, 16000), (16000, 48000), (32000, 16000), (8000, 16000),
-         (44100, 48000), (22050, 16000), (24000, 16000), (96000, 16000), (44100, 22050)]
+         (44100, 48000), (22050, 16000), (24000, 16000), (96000, 16000), (44100, 22050),
+         (48000, 44100), (16000, 44100), (64000, 16000)]
 
 
 def main():
