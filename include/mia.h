@@ -249,6 +249,10 @@ int mia_spectrum_part(const void* z, int64_t rows, int64_t frames, int64_t bins,
 #define MIA_RS_PAD_REFLECT 2
 #define MIA_RS_PAD_SYMMETRIC 3
 #define MIA_RS_PAD_WRAP 4
+#define MIA_RS_PAD_SMOOTH 5        /* the end segments continued as straight lines */
+#define MIA_RS_PAD_LINE 6          /* the line through the first and the last sample */
+#define MIA_RS_PAD_ANTISYMMETRIC 7 /* ... -x1 -x0 | x0 x1 ... */
+#define MIA_RS_PAD_ANTIREFLECT 8   /* point reflection about the end samples */
 /* resample_poly (primitives/resample.py:209-302, which hands float32 rows to
  * scipy.signal.resample_poly at :275): upsample by `up`, FIR-filter, keep every `down`-th
  * sample.  x: device (rows, n_in).  phase_table: device (up, taps_per_phase), row t = the
@@ -267,6 +271,10 @@ int mia_upfirdn(const float* x, int64_t rows, int64_t n_in, const float* phase_t
  * lanes would meet in one LDS bank, rows shorter than one run of outputs): then call
  * mia_upfirdn. */
 int mia_upfirdn_margin(int up, int down, int taps_per_phase, int64_t n_out);
+/* Bytes of LDS one workgroup of mia_upfirdn_shared takes for the ratio (staged samples plus the
+ * table of step constants; at most the CU's 160 KiB), or 0 when the kernel does not apply.
+ * Touches no device.  (Plan query of this library; the reference has no counterpart.) */
+int64_t mia_upfirdn_shared_lds_bytes(int up, int down, int taps_per_phase);
 int mia_upfirdn_shared(const float* x, int64_t rows, int64_t n_in, const float* padded_table,
                        int margin, int up, int down, int taps_per_phase, int64_t skip,
                        int64_t n_out, int pad_mode, float* out, void* stream);

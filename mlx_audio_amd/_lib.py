@@ -25,7 +25,8 @@ MIA_ERR_UNSUPPORTED = -2
 MIA_ERR_HIP = -3
 
 PAD_MODES = {"constant": 0, "edge": 1, "reflect": 2}
-RS_PAD_MODES = {"constant": 0, "edge": 1, "reflect": 2, "symmetric": 3, "wrap": 4}
+RS_PAD_MODES = {"constant": 0, "edge": 1, "reflect": 2, "symmetric": 3, "wrap": 4, "smooth": 5,
+                "line": 6, "antisymmetric": 7, "antireflect": 8}
 EPI_NONE, EPI_WHISPER, EPI_DB = 0, 1, 2
 
 
@@ -96,6 +97,7 @@ SIGNATURES = {
     "mia_upfirdn": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int, c_int, c_int, c_int64,
                             c_int64, c_int, c_void_p, c_void_p]),
     "mia_upfirdn_margin": (c_int, [c_int, c_int, c_int, c_int64]),
+    "mia_upfirdn_shared_lds_bytes": (c_int64, [c_int, c_int, c_int]),
     "mia_upfirdn_shared": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int, c_int, c_int, c_int,
                                    c_int64, c_int64, c_int, c_void_p, c_void_p]),
     "mia_resample_linear": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_double, c_double,

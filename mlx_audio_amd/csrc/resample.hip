@@ -56,6 +56,46 @@ __device__ __forceinline__ float extended_sample(const float* __restrict__ x, lo
       if (j < 0) j += n;
       return x[j];
     }
+    // The four modes below extend by arithmetic on the samples; every operation is a single
+    // float32 one in SciPy's order (scipy/signal/_upfirdn_apply.pyx, _extend_left / _extend_right),
+    // so the results are the same bits.  A row of one sample has no slope or mirror there
+    // (SciPy reads past the row): it extends by its sample here.
+    case MIA_RS_PAD_SMOOTH: {  // the end segments continued as straight lines
+      if (n == 1) return x[0];
+      if (i < 0) return x[0] + (float)i * (x[1] - x[0]);
+      return x[n - 1] + (float)(i - n + 1) * (x[n - 1] - x[n - 2]);
+    }
+    case MIA_RS_PAD_LINE: {  // the line through the first and the last sample
+      if (n == 1) return x[0];
+      const float slope = (x[n - 1] - x[0]) / (float)(n - 1);
+      if (i < 0) return x[0] + (float)i * slope;
+      return x[n - 1] + (float)(i - n + 1) * slope;
+    }
+    case MIA_RS_PAD_ANTISYMMETRIC: {  // ... -x1 -x0 | x0 x1 ... : period 2 n, odd about the ends
+      const long long p = 2 * n;
+      if (i < 0) {
+        const long long j = (-i - 1) % p;
+        return j < n ? -x[j] : x[p - 1 - j];
+      }
+      const long long j = i % p;
+      return j < n ? x[j] : -x[p - 1 - j];
+    }
+    case MIA_RS_PAD_ANTIREFLECT: {  // point reflection about the end samples, repeated
+      if (n == 1) return x[0];
+      const long long p = 2 * (n - 1);
+      if (i < 0) {
+        if (-i < n) return x[0] - (x[-i] - x[0]);
+        const float le = x[0] + (x[0] - x[n - 1]) * (float)((-i - 1) / (n - 1));
+        const long long j = (-i - 1) % p;
+        if (j < n - 1) return le - (x[j + 1] - x[0]);
+        return le - (x[n - 1] - x[p - 1 - j]);
+      }
+      if (i < 2 * n - 1) return x[n - 1] - (x[2 * n - 2 - i] - x[n - 1]);
+      const float re = x[n - 1] + (x[n - 1] - x[0]) * (float)(i / (n - 1) - 1);
+      const long long j = i % p;
+      if (j < n - 1) return re + (x[j] - x[0]);
+      return re + (x[n - 1] - x[p - j]);
+    }
     default:
       return 0.0f;
   }
@@ -553,9 +593,12 @@ static bool sh_plan(int up, int down, int P, ShPlan* pl) {
   const long long dmax5 = ((long long)up - 1 + 4LL * down) / up;  // for the most outputs per step
   if (dmax5 > 2048) return false;
   const long long extra5 = (long long)P + dmax5 + 40 + 4;
-  const long long caps[2] = {19000, 38000};  // floats of LDS: two workgroups per CU, else one
+  // floats of LDS for the staged span AND the table of step constants (kShBt ints per wave-step,
+  // ceil(c * up / r) steps with r >= 4): two workgroups per CU, else one
+  const long long caps[2] = {19000, 38000};
+  const long long per_c = 64LL * down + ((long long)kShBt * up + 3) / 4;
   for (int ci = 0; ci < 2; ++ci) {
-    const long long cmax = (caps[ci] - extra5) / (64LL * down);
+    const long long cmax = (caps[ci] - extra5 - kShBt) / per_c;
     if (cmax < 1) continue;
     long long best_c = 0;
     double best = 1e9;
@@ -596,6 +639,7 @@ static bool sh_plan(int up, int down, int P, ShPlan* pl) {
     pl->span_cap = (int)((64LL * pl->cd + P + dmax + 40 + 4 + 3) & ~3LL);
     pl->margin = (int)dmax + 24;
     const long long nblocks = (U + best_r - 1) / best_r;
+    if (pl->span_cap + kShBt * nblocks > caps[ci]) continue;  // (the estimate above is exact or high)
     pl->threads = (int)(64 * (nblocks < 16 ? nblocks : 16));
     pl->rp = pl->rw = 0;
     return true;
@@ -614,7 +658,8 @@ static bool sh_plan(int up, int down, int P, ShPlan* pl) {
     const long long dmax = ((long long)up - 1 + (long long)(r - 1) * down) / up;
     const long long rw = cd + P + dmax + 48;
     const long long rp = rw | 1;
-    if (rw > 512 || 64 * rp > 38000) return false;  // 32 samples per thread; the CU's LDS
+    // 32 samples per thread; the CU's LDS (span and the step constants of 16 steps)
+    if (rw > 512 || 64 * rp + 3 + kShBt * ((U + r - 1) / r) > 38000) return false;
     if ((64 * U + 8) * (long long)down + up >= 0x7fffffffLL) return false;
     pl->c = (int)c;
     pl->U = (int)U;
@@ -661,7 +706,7 @@ int mia_upfirdn(const float* x, int64_t rows, int64_t n_in, const float* phase_t
   MIA_REQUIRE(rows >= 0 && n_in >= 1 && n_out >= 0, "rows, n_in, n_out must be >= 0, 1, 0");
   MIA_REQUIRE(up >= 1 && down >= 1 && taps_per_phase >= 1 && skip >= 0,
               "up, down, taps_per_phase must be >= 1 and skip >= 0");
-  MIA_REQUIRE(pad_mode >= MIA_RS_PAD_CONSTANT && pad_mode <= MIA_RS_PAD_WRAP,
+  MIA_REQUIRE(pad_mode >= MIA_RS_PAD_CONSTANT && pad_mode <= MIA_RS_PAD_ANTIREFLECT,
               "unknown padding mode %d", pad_mode);
   if (rows == 0 || n_out == 0) return MIA_OK;
   MIA_REQUIRE(x && phase_table && out, "null pointer");
@@ -717,6 +762,10 @@ int mia_upfirdn(const float* x, int64_t rows, int64_t n_in, const float* phase_t
   const size_t lds = sizeof(float) * ((size_t)span_cap + (table_lds ? (size_t)up * (P | 1) : 0));
   // as many workgroups as the device holds at once (the phase table is staged once per
   // workgroup), each walking a contiguous block of runs
+  if (lds > 160 * 1024) {  // (sh_plan keeps its plans below this; checked where the launch is)
+    set_error("resample: the shared-window plan for up %d, down %d needs %zu bytes of LDS", up, down, lds);
+    return MIA_ERR_UNSUPPORTED;
+  }
   int dev = 0, cus = 256;
   MIA_CHECK_HIP(hipGetDevice(&dev));
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
@@ -764,6 +813,13 @@ int mia_upfirdn_margin(int up, int down, int taps_per_phase, int64_t n_out) {
   return pl.margin;
 }
 
+int64_t mia_upfirdn_shared_lds_bytes(int up, int down, int taps_per_phase) {
+  mia::ShPlan pl;
+  if (!mia::sh_plan(up, down, taps_per_phase, &pl)) return 0;
+  return (int64_t)(sizeof(float) * ((size_t)pl.span_cap +
+                                    (size_t)mia::kShBt * ((pl.U + pl.R - 1) / pl.R)) + 16);
+}
+
 int mia_upfirdn_shared(const float* x, int64_t rows, int64_t n_in, const float* padded_table,
                        int margin, int up, int down, int taps_per_phase, int64_t skip,
                        int64_t n_out, int pad_mode, float* out, void* stream) {
@@ -771,7 +827,7 @@ int mia_upfirdn_shared(const float* x, int64_t rows, int64_t n_in, const float* 
   MIA_REQUIRE(rows >= 0 && n_in >= 1 && n_out >= 0, "rows, n_in, n_out must be >= 0, 1, 0");
   MIA_REQUIRE(up >= 1 && down >= 1 && taps_per_phase >= 1 && skip >= 0,
               "up, down, taps_per_phase must be >= 1 and skip >= 0");
-  MIA_REQUIRE(pad_mode >= MIA_RS_PAD_CONSTANT && pad_mode <= MIA_RS_PAD_WRAP,
+  MIA_REQUIRE(pad_mode >= MIA_RS_PAD_CONSTANT && pad_mode <= MIA_RS_PAD_ANTIREFLECT,
               "unknown padding mode %d", pad_mode);
   ShPlan pl;
   if (!sh_plan(up, down, taps_per_phase, &pl)) {
@@ -790,7 +846,11 @@ int mia_upfirdn_shared(const float* x, int64_t rows, int64_t n_in, const float* 
   const long long run = 64LL * pl.U;
   const long long runs_per_row = (n_out + run - 1) / run;
   const long long total_runs = rows * runs_per_row;
-  const size_t lds = sizeof(float) * ((size_t)pl.span_cap + (size_t)kShBt * ((pl.U + pl.R - 1) / pl.R)) + 16;
+  const size_t lds = (size_t)mia_upfirdn_shared_lds_bytes(up, down, taps_per_phase);
+  if (lds > 160 * 1024) {  // (sh_plan keeps its plans below this; checked where the launch is)
+    set_error("resample: the shared-window plan for up %d, down %d needs %zu bytes of LDS", up, down, lds);
+    return MIA_ERR_UNSUPPORTED;
+  }
   int dev = 0, cus = 256;
   MIA_CHECK_HIP(hipGetDevice(&dev));
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);

@@ -49,14 +49,18 @@ def onset_strength(y=None, sr: int = 22050, S=None, n_fft: int = 2048, hop_lengt
     rows, bands, frames = Sb.shape
     dev = Sb.device
     lib = _lib.lib()
+    if frames < lag:
+        # Both slices of the lagged difference are empty (onset.py:131), every later step keeps
+        # the empty envelope, and the closing pad puts `lag` zeros in front of it
+        # (onset.py:170-171): the result has `lag` frames, not `frames`.
+        env = torch.zeros((rows, int(lag)), dtype=torch.float32, device=dev)
+        return env[0] if is_1d else env
     env = torch.empty((rows, frames), dtype=torch.float32, device=dev)
-    n = max(frames - lag, 0)   # the envelope proper; the first `lag` frames are the zero padding
+    n = frames - lag   # the envelope proper; the first `lag` frames are the zero padding
     with torch.cuda.device(dev):
         stream = stream_ptr(dev)
         _lib.check(lib.mia_onset_flux(Sb.data_ptr(), rows, bands, frames, int(lag),
                                       _AGG[aggregate], env.data_ptr(), stream))
-        if frames < lag:
-            env.zero_()
         steps = []
         if max_size > 1:
             steps.append((int(max_size), 0))

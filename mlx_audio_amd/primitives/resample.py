@@ -221,10 +221,10 @@ def _phase_table_dev(up: int, down: int, pre: int, post: int, device, margin: in
 def resample_poly(y, up: int, down: int, axis: int = -1, padtype: str = "constant") -> torch.Tensor:
     """Polyphase resampling by the integer ratio up/down (reference resample.py:209-302).
 
-    padtype: "constant" (zeros), "edge", "reflect", "symmetric", "wrap", or one of "mean",
-    "median", "minimum", "maximum" (that statistic of each row is subtracted before the
-    filter and added back after it).  SciPy's remaining modes ("line", "smooth",
-    "antisymmetric", "antireflect") raise NotImplementedError.
+    padtype: any of SciPy's: "constant" (zeros), "edge", "reflect", "symmetric", "wrap", "line",
+    "smooth", "antisymmetric", "antireflect" (the signal extended past its ends by that rule),
+    or one of "mean", "median", "minimum", "maximum" (that statistic of each row is
+    subtracted before the filter and added back after it).
     """
     _validate_positive(up, "up")
     _validate_positive(down, "down")
@@ -234,8 +234,6 @@ def resample_poly(y, up: int, down: int, axis: int = -1, padtype: str = "constan
     if up == 1 and down == 1:
         return y
     if padtype not in _lib.RS_PAD_MODES and padtype not in _BACKGROUND:
-        if padtype in ("line", "smooth", "antisymmetric", "antireflect"):
-            raise NotImplementedError(f"padtype '{padtype}' is not built")
         raise ValueError(
             "padtype must be one of: maximum, mean, median, minimum, constant, wrap, edge, "
             "smooth, symmetric, reflect, antisymmetric, antireflect, line")

@@ -173,3 +173,23 @@ def test_upfirdn_margin_is_host_only_and_says_where_the_shared_window_kernel_app
     for up, down, taps in ((160, 441, 56), (3, 1, 21), (2, 1, 21), (160, 147, 21), (320, 441, 28),
                            (1, 4, 81), (3, 8, 55)):
         assert lib.mia_upfirdn_margin(up, down, taps, long_row) > 0, (up, down)
+
+
+def test_shared_window_plans_fit_the_lds_for_every_ratio():
+    """The shared-window kernel's LDS holds the staged samples AND a table of step constants
+    that grows with up: whatever ratio mia_upfirdn_margin accepts must fit a CU's 160 KiB
+    (integer upsampling by 32, 48, 147 and 100/3 once did not)."""
+    lib = _lib.lib()
+    long_row = 10 ** 7
+    worst = 0
+    for up in list(range(1, 65)) + [80, 96, 100, 147, 160, 200, 320, 441, 640, 1000]:
+        for down in (1, 2, 3, 5, 7, 8, 147, 160, 441):
+            taps = 20 * max(up, down) // up + 2
+            lds = lib.mia_upfirdn_shared_lds_bytes(up, down, taps)
+            assert (lds > 0) == (lib.mia_upfirdn_margin(up, down, taps, long_row) > 0), (up, down)
+            assert lds <= 160 * 1024, (up, down, lds)
+            worst = max(worst, lds)
+    assert worst > 64 * 1024   # the sweep does reach plans with large spans
+    for up, down in ((32, 1), (48, 1), (147, 1), (100, 3)):
+        assert 0 < lib.mia_upfirdn_shared_lds_bytes(up, down, 22) <= 160 * 1024
+

@@ -42,6 +42,23 @@ def test_envelope_filters(gpu, kw):
     np.testing.assert_allclose(got, want, rtol=0, atol=ATOL)
 
 
+@pytest.mark.parametrize("frames,lag", [(3, 5), (1, 2), (4, 4), (5, 4)])
+def test_fewer_frames_than_the_lag(gpu, frames, lag):
+    """With no more frames than `lag` both slices of the lagged difference are empty and the
+    closing pad leaves `lag` zeros (reference onset.py:131,170-171): the envelope has `lag`
+    frames then, whatever the aggregate and the filters; one frame more gives `frames`."""
+    rng = np.random.default_rng(frames + 10 * lag)
+    S = np.abs(rng.standard_normal((2, 16, frames))).astype(np.float32)
+    for aggregate in ("mean", "median", "max"):
+        for kw in ({}, {"max_size": 3}, {"detrend": True}):
+            want = orc.onset_strength(S=S, lag=lag, aggregate=aggregate, **kw)
+            got = onset_strength(S=_dev(S, gpu), lag=lag, aggregate=aggregate, **kw).cpu().numpy()
+            assert got.shape == want.shape == (2, max(frames, lag)), (aggregate, kw)
+            np.testing.assert_allclose(got, want, rtol=0, atol=ATOL)
+    one = onset_strength(S=_dev(S[0], gpu), lag=lag).cpu().numpy()
+    assert one.shape == (max(frames, lag),)
+
+
 @pytest.mark.parametrize("n_fft,hop,n_mels", [(2048, 512, 128), (1024, 256, 64)])
 def test_from_a_waveform_and_detection(gpu, n_fft, hop, n_mels):
     sr = 22050

@@ -44,15 +44,18 @@ def test_resample_poly_reduces_the_ratio_and_takes_1d_and_axis(gpu):
                                   orc.resample_poly(x, 1, 2))
 
 
-@pytest.mark.parametrize("padtype", ["edge", "reflect", "symmetric", "wrap"])
+@pytest.mark.parametrize("padtype", ["edge", "reflect", "symmetric", "wrap", "line", "smooth",
+                                     "antisymmetric", "antireflect"])
 @pytest.mark.parametrize("up,down", [(1, 2), (3, 1), (160, 441), (147, 160)])
 def test_resample_poly_extension_modes(gpu, padtype, up, down):
     rng = np.random.default_rng(11)
     for n in (1, 2, 7, 50, 3001):   # rows far shorter than the filter wrap around many times
         x = (rng.standard_normal((2, n)) + 3.0).astype(np.float32)
         # SciPy divides by the reflection period 2*(n-1) = 0 for a one-sample row and the
-        # process dies with SIGFPE; here that row is extended by its only sample.
-        ref_mode = "edge" if (padtype == "reflect" and n == 1) else padtype
+        # process dies with SIGFPE (reflect, antireflect), or reads past the row (smooth) or
+        # divides 0 by 0 (line); here that row is extended by its only sample.
+        one = n == 1 and padtype in ("reflect", "antireflect", "smooth", "line")
+        ref_mode = "edge" if one else padtype
         want = orc.resample_poly(x, up, down, padtype=ref_mode)
         got = resample_poly(_dev(x, gpu), up, down, padtype=padtype).cpu().numpy()
         np.testing.assert_array_equal(got, want, err_msg=f"{padtype} {up}/{down} n={n}")
@@ -68,8 +71,8 @@ def test_resample_poly_background_modes(gpu, padtype):
         # the row statistic is a device reduction (summation order differs for the mean)
         tol = 0.0 if padtype in ("minimum", "maximum") else 2e-6
         np.testing.assert_allclose(got, want, rtol=0, atol=tol)
-    with pytest.raises(NotImplementedError):
-        resample_poly(_dev(x, gpu), 2, 3, padtype="line")
+    with pytest.raises(ValueError, match="padtype must be one of"):
+        resample_poly(_dev(x, gpu), 2, 3, padtype="bogus")
 
 
 def test_resample_poly_nonfinite_samples_stay_local(gpu):
@@ -86,7 +89,10 @@ SHARED_RATIOS = [(160, 441), (1, 3), (3, 1), (1, 2), (2, 1), (160, 147), (2, 3),
                  (1, 6), (5, 7),
                  # lane spacings that are a multiple of four samples: the row-per-lane layout
                  # (long filters only: 48 -> 44.1 kHz stays on the per-output kernel)
-                 (1, 4), (3, 8)]
+                 (1, 4), (3, 8),
+                 # integer upsampling by a large factor: the table of step constants is most
+                 # of the workgroup's LDS
+                 (32, 1), (48, 1), (147, 1), (100, 3)]
 
 
 def _taps_per_phase(n_in, up, down):
@@ -106,7 +112,7 @@ def test_shared_window_kernel_is_bit_identical_to_scipy(gpu, up, down):
     P, n_out = _taps_per_phase(n, up, down)
     assert _lib.lib().mia_upfirdn_margin(up, down, P, n_out) > 0   # the path under test
     x = rng.standard_normal((5, n)).astype(np.float32)
-    for padtype in ("constant", "reflect", "wrap"):
+    for padtype in ("constant", "reflect", "wrap", "line", "antireflect"):
         want = orc.resample_poly(x, up, down, padtype=padtype)
         got = resample_poly(_dev(x, gpu), up, down, padtype=padtype).cpu().numpy()
         np.testing.assert_array_equal(got, want, err_msg=f"{up}/{down} {padtype}")
