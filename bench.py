@@ -2,6 +2,11 @@
 
     python bench.py --gpus N --steps K --warmup W [--workload NAME]
 
+At N = 1 the default run also times, after the headline's timed region and outside its number,
+the other BASELINE configurations (clap64, mfcc40, htdemucs) for a few steps each and attaches
+them as "secondary"; "roofline.traffic" is a committed counter measurement that is reported
+only while the kernel sources it was taken on are unchanged ("roofline.traffic_source").
+
 One step = one pass of the hot path over one batch of synthetic clips that is
 already resident in HBM.  With N > 1 (launched by torch.distributed.run, one
 rank per GPU) every rank processes its own batch — clips shard with no
@@ -233,15 +238,51 @@ KERNEL_OF = {
 
 
 def measured_traffic(workload: str, clips: int):
-    """HBM bytes per step from the committed PMC passes (FETCH_SIZE doubled as
-    gfx950 needs, plus WRITE_SIZE), or None if that workload/size has no pass."""
-    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    try:
-        table = json.load(open(path))
-    except (OSError, ValueError):
-        return None
-    entry = table.get(f"{workload}:{clips}")
-    return None if entry is None else entry.get("hbm_bytes_per_step")
+    """(HBM bytes per step, provenance) from the committed PMC passes (FETCH_SIZE doubled as
+    gfx950 needs, plus WRITE_SIZE).  The bytes are None when that workload / size has no pass
+    or when a kernel source has changed since the pass (mlx_audio_amd/provenance.py)."""
+    from mlx_audio_amd.provenance import measured_traffic as lookup
+
+    return lookup(workload, clips)
+
+
+DEFAULT_CLIPS = {"whisper128": 1024, "clap64": 1024, "mfcc40": 4096, "htdemucs": 128,
+                 "resample": 512, "resample_fft": 64, "features": 512, "contrast": 512,
+                 "onset": 4096, "griffinlim": 64, "spectral_gate": 64, "demucs_front": 16,
+                 "features_y": 512, "features_all": 512, "whisper_stem": 64}
+SECONDARY = ("clap64", "mfcc40", "htdemucs")  # BASELINE.json configs[3], [4], [2] at their per-GPU sizes
+
+
+def run_secondary(device, seed: int, steps: int = 5, warmup: int = 3) -> dict:
+    """The other BASELINE configurations, a few steps each, after (and outside) the headline's
+    timed region; every workload's tensors are released before the next one is built."""
+    import torch
+
+    res = {}
+    for name in SECONDARY:
+        clips = DEFAULT_CLIPS[name]
+        step, units, abytes, desc, metric = make_workload(name, clips, device, seed)
+        for _ in range(warmup):
+            out = step()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(steps):
+            out = step()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / steps
+        gbs = abytes / (ms * 1e-3) / 1e9
+        traffic, src = measured_traffic(name, clips)
+        res[name] = {"workload": desc, "metric": metric, "clips_per_gpu": clips, "steps": steps,
+                     "ms_per_step": ms, "value": units / (ms * 1e-3),
+                     "unit": "track-hours/s" if name == "htdemucs" else "audio-hours/s",
+                     "algorithmic_bytes": abytes, "achieved_GBps": gbs, "frac": gbs / HBM_PEAK_GBS,
+                     "traffic": traffic, "traffic_source": src["status"],
+                     "kernel": KERNEL_OF.get(name)}
+        del step, out
+        torch.cuda.empty_cache()
+    return res
 
 
 def cpu_baseline(budget_s: float = 8.0) -> dict:
@@ -364,6 +405,9 @@ def main() -> None:
     ap.add_argument("--workload", default="whisper128")
     ap.add_argument("--clips", type=int, default=None, help="clips (rows) per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the short runs of the other BASELINE configurations that follow the "
+                         "default workload's timed region at N = 1")
     ap.add_argument("--gather", action="store_true",
                     help="also time the run with every step's features collected on rank 0 "
                          "(chunked sends on a side stream, overlapping the next step; N > 1)")
@@ -400,9 +444,7 @@ def main() -> None:
         print(f"[bench] --gpus {args.gpus} but the process group has {n_gpus} rank(s)",
               file=sys.stderr)
 
-    default_clips = {"whisper128": 1024, "clap64": 1024, "mfcc40": 4096, "htdemucs": 128,
-                     "resample": 512, "resample_fft": 64, "features": 512, "contrast": 512, "onset": 4096, "griffinlim": 64, "spectral_gate": 64, "demucs_front": 16, "features_y": 512, "features_all": 512, "whisper_stem": 64}
-    clips = args.clips or default_clips.get(args.workload, 1024)
+    clips = args.clips or DEFAULT_CLIPS.get(args.workload, 1024)
     step, units, abytes, desc, metric = make_workload(args.workload, clips, device, 1234 + rank)
 
     def barrier():
@@ -466,9 +508,17 @@ def main() -> None:
     del out
     elapsed = max_over_ranks(elapsed, device)
 
+    secondary = None
+    if (rank == 0 and n_gpus == 1 and args.workload == "whisper128" and args.clips is None
+            and not args.no_secondary):
+        del step
+        torch.cuda.empty_cache()
+        secondary = run_secondary(device, 1234)
+
     if rank == 0:
         value = n_gpus * units * args.steps / elapsed
         achieved = abytes / (dev_ms * 1e-3) / 1e9
+        traffic, traffic_source = measured_traffic(args.workload, clips)
         line = {
             "metric": metric,
             "value": value,
@@ -491,7 +541,8 @@ def main() -> None:
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": measured_traffic(args.workload, clips),
+                "traffic": traffic,
+                "traffic_source": traffic_source,
                 "kernel": KERNEL_OF.get(args.workload, "fwd_kernel") + ", timed with stream "
                           "events around each step (every launch of the step, e.g. the key "
                           "initialisation and the floor pass of the mel workloads, is inside "
@@ -508,6 +559,8 @@ def main() -> None:
                                      "flops_per_step": WORKLOAD_FLOPS[args.workload]})
         if gather is not None:
             line["gather"] = gather
+        if secondary is not None:
+            line["secondary"] = secondary
         if n_gpus == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))

@@ -572,8 +572,8 @@ __global__ __launch_bounds__(w400::WG, 4) void logmel400_kernel(
 
 // =============================================================================================
 // The same front-end with the samples brought into LDS by LDS-DMA loads (global_load_lds_dwordx4)
-// instead of through registers, for the compiled filterbanks and clips whose rows are 16-byte
-// aligned.  Differences from logmel400_kernel:
+// instead of through registers, for the compiled filterbanks (clip rows at any float
+// alignment).  Differences from logmel400_kernel:
 //   * a wave's 880 samples have a FIXED staging area of their own at the end of the wave's
 //     region (it doubles as the exchange area of frames 2, 3), so the loads of tile i + 1 can be
 //     issued as soon as pass 2 of tile i has read its exchange back - before the barrier and
@@ -1219,10 +1219,10 @@ int launch_logmel400(const FwdParams& p0, const W400Tables& tb, hipStream_t s) {
   grid = (total + p.tiles_per_wg - 1) / p.tiles_per_wg;
   // The straight-line sweep exists for Whisper's two banks with the Whisper epilogue.
   const int bank = (p.epi == MIA_EPI_WHISPER && !tb.force_table_sweep) ? tb.compiled_bank : 0;
-  // LDS-DMA staging needs 16-byte aligned sources: every clip row must start on one.
-  const bool dma = bank != 0 && !tb.force_vgpr_staging &&
-                   (reinterpret_cast<unsigned long long>(p.y) & 15ull) == 0 && p.T % 4 == 0 &&
-                   p.pad % 4 == 0;
+  // LDS-DMA staging: a lane's 16-byte source only has to be float-aligned
+  // (global_load_lds_dwordx4 reads rows at any 4-byte phase at the same rate), so odd clip
+  // lengths stay on this kernel.
+  const bool dma = bank != 0 && !tb.force_vgpr_staging;
   if (tb.force_mfma && tb.mfma_a != nullptr && p.epi == MIA_EPI_WHISPER) {
     launch_w400<MIA_EPI_WHISPER, W400_MFMA>(p, tb, (unsigned)grid, s);
   } else if (dma) {

@@ -197,3 +197,28 @@ def test_nan_and_inf_clips_cross_lane_pass2():
         lib.mia_plan_set_option(plan.handle, b"w400_dpp_pass2", 0)
     assert np.allclose(got, want, rtol=0, atol=4e-6, equal_nan=True)
     assert np.isnan(got[1]).all() and np.isnan(got[2]).all() and np.isfinite(got[0]).all()
+
+
+def test_paths_behind_the_headline_kernel_keep_parity():
+    """What does NOT run on the LDS-DMA kernel at n_fft 400 / hop 160 - a filterbank other than
+    Whisper's two, the dB epilogue - takes the register-staging kernel with the table-driven
+    sweep; odd clip lengths (rows at every 4-byte phase) stay on the LDS-DMA kernel.  Each against
+    the oracle, with the tolerance of the headline path (profiles/r03_w400_paths.txt has their times)."""
+    import oracle.spectral as o
+    from mlx_audio_amd.frontends import compute_log_mel_spectrogram
+    from mlx_audio_amd.primitives import melspectrogram, power_to_db
+
+    rng = np.random.default_rng(400)
+    # odd length, batch: clip b starts b * 480001 floats in
+    x = rng.standard_normal((6, 480001)).astype(np.float32)
+    got = compute_log_mel_spectrogram(torch.from_numpy(x).cuda(), n_mels=128, per_clip=True).cpu().numpy()
+    for b in (0, 3, 5):
+        assert np.abs(got[b] - o.compute_log_mel_spectrogram(x[b], n_mels=128)).max() <= 1e-4, b
+    # a 64-filter bank on the same framing, linear and dB
+    kw = dict(sr=16000, n_fft=400, hop_length=160, n_mels=64, fmin=20.0, fmax=7600.0)
+    y = x[:2, :160000]
+    m = melspectrogram(torch.from_numpy(y).cuda(), **kw)
+    want = o.melspectrogram(y, **kw)
+    np.testing.assert_allclose(m.cpu().numpy(), want, rtol=1e-4, atol=1e-5 * want.max())
+    db = power_to_db(m, top_db=80.0).cpu().numpy()
+    assert np.abs(db - o.power_to_db(want, top_db=80.0)).max() <= 2e-3

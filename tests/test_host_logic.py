@@ -4,6 +4,8 @@ primitives/stft.py:190-199, mel.py:227-237, mfcc.py:226-231, convert.py:49-52),
 host table helpers, the plan-cache key, and the refusal to run without a GPU.
 """
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -11,6 +13,8 @@ import torch
 import oracle.spectral as o
 from mlx_audio_amd import _lib, _runtime, primitives
 from mlx_audio_amd.primitives import windows as win_mod
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 NO_GPU = not torch.cuda.is_available()
 
@@ -113,3 +117,42 @@ def test_product_never_imports_the_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+
+
+def test_traffic_is_reported_only_for_unchanged_kernel_sources(tmp_path):
+    """bench.py's roofline.traffic comes from committed counter passes; an entry counts only
+    while every source file it names still has the blob hash recorded with it."""
+    import json
+    import subprocess
+
+    from mlx_audio_amd import provenance as pv
+
+    src = tmp_path / "mlx_audio_amd" / "csrc"
+    src.mkdir(parents=True)
+    (tmp_path / "profiles").mkdir()
+    f = src / "onset.hip"
+    f.write_text("__global__ void k() {}\n")
+    # the hash is git's own
+    want = subprocess.run(["git", "hash-object", str(f)], capture_output=True, text=True).stdout.strip()
+    assert pv.blob_hash(str(f)) == want
+    hashes = pv.source_hashes("onset", root=str(tmp_path))
+    assert hashes == {"mlx_audio_amd/csrc/onset.hip": want}
+    table = {"onset:4096": {"hbm_bytes_per_step": 123, "kernel_sources": hashes, "profile": "p.txt"},
+             "contrast:512": {"hbm_bytes_per_step": 5}}
+    (tmp_path / "profiles" / "pmc_traffic.json").write_text(json.dumps(table))
+    got, info = pv.measured_traffic("onset", 4096, root=str(tmp_path))
+    assert got == 123 and info["status"].startswith("sources match") and info["profile"] == "p.txt"
+    assert pv.measured_traffic("onset", 512, root=str(tmp_path))[0] is None        # no pass at that size
+    got, info = pv.measured_traffic("contrast", 512, root=str(tmp_path))          # no hashes recorded
+    assert got is None and "no source hashes" in info["status"]
+    f.write_text("__global__ void k() { }\n")                                     # the kernel changed
+    got, info = pv.measured_traffic("onset", 4096, root=str(tmp_path))
+    assert got is None and info["status"].startswith("stale") and "onset.hip" in info["status"]
+    # every bench workload with a counter entry names its sources
+    committed = json.load(open(os.path.join(ROOT, pv.TRAFFIC_FILE)))
+    for key in committed:
+        if not key.startswith("_"):
+            assert key.split(":")[0] in pv.WORKLOAD_SOURCES, key
+    for names in pv.WORKLOAD_SOURCES.values():
+        for name in names:
+            assert os.path.exists(os.path.join(ROOT, pv.CSRC, name)), name
