@@ -193,32 +193,41 @@ def make_workload(name: str, clips: int, device, seed: int):
                 clips * 30.0 / 3600.0, abytes,
                 f"centroid + bandwidth + roll-off + flatness from the waveform in one launch, "
                 f"{clips} x 30 s @16 kHz, n_fft 2048 hop 512", "spectral features (from audio) audio-hours/sec")
-    if name == "whisper_stem":
+    if name in ("whisper_stem", "whisper_stem_f16"):
         from mlx_audio_amd.frontends import WhisperEncoderStem, sinusoids
 
+        # whisper_stem: float32 weights in float32 arithmetic (the reference's default);
+        # whisper_stem_f16: the float16-checkpoint arithmetic, opted into
+        prec = "f16" if name.endswith("_f16") else "f32"
         n_mels, n_state, frames = 128, 1280, 3000
         mel = torch.randn((clips, n_mels, frames), generator=gen, device=device, dtype=torch.float32) * 0.5
         w1 = torch.randn((n_state, 3, n_mels), generator=gen, device=device) / (3 * n_mels) ** 0.5
         w2 = torch.randn((n_state, 3, n_state), generator=gen, device=device) / (3 * n_state) ** 0.5
         b1 = 0.1 * torch.randn((n_state,), generator=gen, device=device)
         b2 = 0.1 * torch.randn((n_state,), generator=gen, device=device)
-        stem = WhisperEncoderStem(w1, b1, w2, b2, sinusoids(frames // 2, n_state))
-        abytes = clips * (n_mels * frames * 4 + (frames // 2) * n_state * 2)
+        stem = WhisperEncoderStem(w1, b1, w2, b2, sinusoids(frames // 2, n_state), precision=prec)
+        osz = 2 if prec == "f16" else 4
+        abytes = clips * (n_mels * frames * 4 + (frames // 2) * n_state * osz)
         # multiply-adds of the two convolutions, 2 flops each
         WORKLOAD_FLOPS[name] = 2.0 * clips * (frames * n_state * 3 * n_mels + (frames // 2) * n_state * 3 * n_state)
+        arith = ("float16 operands, float32 accumulation, float16 out" if prec == "f16" else
+                 "float32 operands on the float32 matrix instruction, float32 out")
         return (lambda: stem(mel), clips * 30.0 / 3600.0, abytes,
                 f"Whisper-large-v3 encoder stem (conv1 128->1280 k3 + GELU + conv2 1280->1280 k3 s2 + GELU + "
-                f"positional embedding) on {clips} log-mel spectrograms (128 x 3000), float16 operands, "
-                "float32 accumulation, float16 out", "Whisper encoder stem audio-hours/sec")
+                f"positional embedding) on {clips} log-mel spectrograms (128 x 3000), {arith}",
+                "Whisper encoder stem audio-hours/sec")
     raise SystemExit(f"unknown workload {name}")
 
 
 WORKLOAD_FLOPS: dict = {}   # workloads bound by the matrix cores: flops per step
 MFMA_F16_PEAK_TFLOPS = 2500.0  # MI355X dense f16 / bf16 matrix peak
+MFMA_F32_PEAK_TFLOPS = 157.3   # float32-input matrix instructions: the vector rate
 
 KERNEL_OF = {
-    "whisper_stem": "stem_gemm_kernel (implicit-GEMM Conv1d on v_mfma_f32_32x32x16_f16, LDS-DMA operand "
+    "whisper_stem": "stem_gemm_kernel<float> (implicit-GEMM Conv1d on v_mfma_f32_32x32x2_f32, LDS-DMA operand "
                     "tiles, fused bias + GELU + embedding) x 2 after stem_prep_kernel",
+    "whisper_stem_f16": "stem_gemm_kernel<half> (implicit-GEMM Conv1d on v_mfma_f32_32x32x16_f16, LDS-DMA "
+                        "operand tiles, fused bias + GELU + embedding) x 2 after stem_prep_kernel",
     "whisper128": "logmel400d_kernel (fused pad+frame+window+rFFT-400+128-mel+log10; LDS-DMA staging, compiled mel sweep, line-aligned stores)",
     "clap64": "fwd_kernel<1024, mel> (fused pad+frame+window+rFFT+mel+dB)",
     "mfcc40": "fwd_kernel<2048, mel> (fused rFFT+mel+dB) followed by dct2_mfma_kernel",
@@ -249,7 +258,7 @@ def measured_traffic(workload: str, clips: int):
 DEFAULT_CLIPS = {"whisper128": 1024, "clap64": 1024, "mfcc40": 4096, "htdemucs": 128,
                  "resample": 512, "resample_fft": 64, "features": 512, "contrast": 512,
                  "onset": 4096, "griffinlim": 64, "spectral_gate": 64, "demucs_front": 16,
-                 "features_y": 512, "features_all": 512, "whisper_stem": 64}
+                 "features_y": 512, "features_all": 512, "whisper_stem": 64, "whisper_stem_f16": 64}
 SECONDARY = ("clap64", "mfcc40", "htdemucs")  # BASELINE.json configs[3], [4], [2] at their per-GPU sizes
 
 
@@ -553,9 +562,11 @@ def main() -> None:
         }
         if args.workload in WORKLOAD_FLOPS:
             tf = WORKLOAD_FLOPS[args.workload] / (dev_ms * 1e-3) / 1e12
-            line["dtype"] = "f16 (f32 accumulate)"
-            line["roofline"].update({"bound": "mfma", "achieved": tf, "peak": MFMA_F16_PEAK_TFLOPS,
-                                     "unit": "TFLOP/s", "frac": tf / MFMA_F16_PEAK_TFLOPS,
+            half = args.workload.endswith("_f16")
+            peak = MFMA_F16_PEAK_TFLOPS if half else MFMA_F32_PEAK_TFLOPS
+            line["dtype"] = "f16 (f32 accumulate)" if half else "f32"
+            line["roofline"].update({"bound": "mfma", "achieved": tf, "peak": peak,
+                                     "unit": "TFLOP/s", "frac": tf / peak,
                                      "flops_per_step": WORKLOAD_FLOPS[args.workload]})
         if gather is not None:
             line["gather"] = gather

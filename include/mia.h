@@ -495,23 +495,31 @@ int mia_normalize_rows_sums(const float* x, int64_t rows, int64_t n, float eps, 
  * What AudioEncoder.__call__ does before its transformer blocks: x = mel^T (frames, n_mels);
  * gelu(conv1(x)) with Conv1d(n_mels, n_state, kernel 3, padding 1); gelu(conv2(.)) with
  * Conv1d(n_state, n_state, kernel 3, stride 2, padding 1); + positional_embedding[:frames'].
- * GELU is the exact (erf) form of mlx.nn.gelu.  Arithmetic: float16 operands on the matrix
- * cores with float32 accumulation, float32 bias / GELU / embedding (the precision of a
- * float16 checkpoint; a float32 checkpoint is rounded to float16 by mia_whisper_stem_pack).
+ * GELU is the exact (erf) form of mlx.nn.gelu.  `precision` chooses the arithmetic of the two
+ * convolutions: MIA_STEM_F32 keeps weights, spectrogram and the intermediate in float32 and
+ * multiplies on the float32 matrix instruction (v_mfma_f32_32x32x2_f32: a chain of fused
+ * multiply-adds in float32) - what the reference's nn.Conv1d computes on a float32 checkpoint,
+ * its default; MIA_STEM_F16 rounds weights, spectrogram and the conv1 -> GELU intermediate to
+ * float16 and accumulates in float32 (the precision of a float16 checkpoint, 16 x the rate).
+ * Bias, GELU and embedding are float32 either way.
  * conv*_w are in the reference's own layout (out_channels, kernel, in_channels), float32,
  * device memory; `packed` (mia_whisper_stem_weight_bytes bytes, 16-byte aligned device memory)
- * receives the float16 operand form once per model.  mel: device float32 (clips, n_mels,
- * frames); out: device (clips, (frames - 1) / 2 + 1, n_state), float16 when out_f16 else
- * float32; pos: device float32 (>= out frames, n_state) or NULL; workspace:
+ * receives the operand form of that precision once per model.  mel: device float32 (clips,
+ * n_mels, frames); out: device (clips, (frames - 1) / 2 + 1, n_state), float16 when out_f16
+ * else float32; pos: device float32 (>= out frames, n_state) or NULL; workspace:
  * mia_whisper_stem_workspace_bytes bytes of device memory.  n_state must be a multiple of 128
  * (every Whisper size is); clips * frames < 2^31 per call. */
-size_t mia_whisper_stem_weight_bytes(int n_mels, int n_state);
-int mia_whisper_stem_pack(const float* conv1_w, const float* conv2_w, int n_mels, int n_state, void* packed,
-                          void* stream);
-size_t mia_whisper_stem_workspace_bytes(int64_t clips, int64_t frames, int n_mels, int n_state);
+#define MIA_STEM_F16 0
+#define MIA_STEM_F32 1
+size_t mia_whisper_stem_weight_bytes(int n_mels, int n_state, int precision);
+int mia_whisper_stem_pack(const float* conv1_w, const float* conv2_w, int n_mels, int n_state,
+                          int precision, void* packed, void* stream);
+size_t mia_whisper_stem_workspace_bytes(int64_t clips, int64_t frames, int n_mels, int n_state,
+                                        int precision);
 int mia_whisper_stem(const float* mel, int64_t clips, int64_t frames, int n_mels, int n_state,
-                     const void* packed, const float* conv1_b, const float* conv2_b, const float* pos,
-                     void* out, int out_f16, void* workspace, size_t workspace_bytes, void* stream);
+                     int precision, const void* packed, const float* conv1_b, const float* conv2_b,
+                     const float* pos, void* out, int out_f16, void* workspace, size_t workspace_bytes,
+                     void* stream);
 
 #ifdef __cplusplus
 }

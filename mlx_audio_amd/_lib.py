@@ -28,6 +28,7 @@ PAD_MODES = {"constant": 0, "edge": 1, "reflect": 2}
 RS_PAD_MODES = {"constant": 0, "edge": 1, "reflect": 2, "symmetric": 3, "wrap": 4, "smooth": 5,
                 "line": 6, "antisymmetric": 7, "antireflect": 8}
 EPI_NONE, EPI_WHISPER, EPI_DB = 0, 1, 2
+STEM_F16, STEM_F32 = 0, 1
 
 
 class PlanDesc(ctypes.Structure):
@@ -152,11 +153,11 @@ SIGNATURES = {
     "mia_onset_flux": (c_int, [c_void_p, c_int64, c_int, c_int64, c_int, c_int, c_void_p, c_void_p]),
     "mia_envelope_filter": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_void_p,
                                     c_int64, c_void_p]),
-    "mia_whisper_stem_weight_bytes": (c_size_t, [c_int, c_int]),
-    "mia_whisper_stem_pack": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
-    "mia_whisper_stem_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int, c_int]),
-    "mia_whisper_stem": (c_int, [c_void_p, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p,
-                                 c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+    "mia_whisper_stem_weight_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "mia_whisper_stem_pack": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "mia_whisper_stem_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int, c_int, c_int]),
+    "mia_whisper_stem": (c_int, [c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_void_p, c_void_p,
+                                 c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "mia_resample_fft_table_bytes": (c_size_t, [c_int64, c_int64]),
     "mia_resample_fft_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int64]),
     "mia_resample_fft_tables": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),

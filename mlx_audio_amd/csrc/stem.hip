@@ -22,23 +22,32 @@
 // The weight operand is the MFMA's A (rows = output channels), so a lane of the result holds
 // four consecutive channels of one frame: bias and embedding are float4 loads, the float16
 // result one 8-byte LDS store.
+//
+// Two operand precisions share the kernel.  MIA_STEM_F16: weights, spectrogram and the
+// conv1 -> GELU intermediate rounded to float16 (the arithmetic of a float16 checkpoint).
+// MIA_STEM_F32: everything stays float32 and the products run on v_mfma_f32_32x32x2_f32, whose
+// result equals a chain of fused multiply-adds in float32 - the arithmetic of the reference's
+// nn.Conv1d on a float32 checkpoint (its default), at 1/16 of the float16 rate.  The LDS tiles
+// are the same bytes either way (128-byte rows = 64 halves or 32 floats of K); a lane's 16-byte
+// fragment is then four consecutive k of its row, fed to four successive MFMAs (the two lane
+// halves take different chunks, which only permutes the order of the sum over k).
 #include "mia_internal.h"
 
 namespace mia {
 namespace stem {
-constexpr int BK = 64;  // halves of K per step: 128-byte operand rows in LDS
+constexpr int BKB = 128;  // bytes of K per step: the operand rows in LDS
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef float f16v __attribute__((ext_vector_type(16)));
 
 struct Gemm {
-  const _Float16* act;  // (clips, rows_in, cin): zero row, frames, zero row
+  const void* act;      // (clips, rows_in, cin): zero row, frames, zero row
   long long rows_in;
-  int cin;              // halves per row, a multiple of 64
+  int cin;              // elements per row, a multiple of a 128-byte K-step (64 halves / 32 floats)
   int stride;           // 1 or 2
   int t_out;            // output frames per clip
   int m_total;          // clips * t_out
-  const _Float16* w;    // (n, 3 * cin)
+  const void* w;        // (n, 3 * cin)
   const float* bias;    // (n)
   const float* pos;     // (t_out, n) or null
   int n;                // a multiple of 128
@@ -95,10 +104,12 @@ struct StemTile {
 using StemTile128 = StemTile<2, 2, 2, 2, 2>;  // 128 x 128, 4 waves, two workgroups per CU
 using StemTile256 = StemTile<2, 4, 4, 2, 1>;  // 256 x 256, 8 waves, one workgroup per CU
 
-template <class TL, bool OUT_F16>
+template <class TL, class ET, bool OUT_F16>
 __global__ __launch_bounds__(TL::WG, TL::OCC) void stem_gemm_kernel(stem::Gemm p) {
   using namespace stem;
   constexpr int BN = TL::BN, BM = TL::BM, WG = TL::WG;
+  constexpr bool F32 = sizeof(ET) == 4;
+  constexpr int ES = (int)sizeof(ET);  // bytes per operand element
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -115,13 +126,13 @@ __global__ __launch_bounds__(TL::WG, TL::OCC) void stem_gemm_kernel(stem::Gemm p
 
   // ---- sources of this thread's DMA pieces: piece s = (P wv + i) * 64 + lane of a tile is
   // LDS slot s = row * 8 + c'; it holds the 16 bytes of chunk c = c' ^ ((row >> 1) & 7) ----
-  const _Float16* wsrc[TL::PW];
-  const _Float16* asrc[TL::PA];
+  const char* wsrc[TL::PW];
+  const char* asrc[TL::PA];
 #pragma unroll
   for (int i = 0; i < TL::PW; ++i) {
     const int s = (TL::PW * wv + i) * 64 + lane;
     const int row = s >> 3, c = (s & 7) ^ ((row >> 1) & 7);
-    wsrc[i] = p.w + ((size_t)(n0 + row) * K + 8 * c);
+    wsrc[i] = static_cast<const char*>(p.w) + ((size_t)(n0 + row) * K * ES + 16 * c);
   }
 #pragma unroll
   for (int i = 0; i < TL::PA; ++i) {
@@ -130,7 +141,8 @@ __global__ __launch_bounds__(TL::WG, TL::OCC) void stem_gemm_kernel(stem::Gemm p
     int m = m0 + row;
     m = m < p.m_total ? m : p.m_total - 1;  // rows past the end repeat the last one; never stored
     const int clip = m / p.t_out, t = m - clip * p.t_out;
-    asrc[i] = p.act + (((size_t)clip * p.rows_in + (size_t)p.stride * t) * p.cin + 8 * c);
+    asrc[i] = static_cast<const char*>(p.act) +
+              (((size_t)clip * p.rows_in + (size_t)p.stride * t) * p.cin * ES + 16 * c);
   }
   const unsigned lds0 = (unsigned)(unsigned long long)(smem);
   const unsigned wdst = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + 1024u * TL::PW * wv));
@@ -138,9 +150,9 @@ __global__ __launch_bounds__(TL::WG, TL::OCC) void stem_gemm_kernel(stem::Gemm p
       (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + TL::W_BYTES + 1024u * TL::PA * wv));
   auto issue = [&](int ks, int buf) {
 #pragma unroll
-    for (int i = 0; i < TL::PW; ++i) dma16(wsrc[i] + ks * BK, wdst + buf * TL::BUF_BYTES + 1024u * i);
+    for (int i = 0; i < TL::PW; ++i) dma16(wsrc[i] + ks * BKB, wdst + buf * TL::BUF_BYTES + 1024u * i);
 #pragma unroll
-    for (int i = 0; i < TL::PA; ++i) dma16(asrc[i] + ks * BK, adst + buf * TL::BUF_BYTES + 1024u * i);
+    for (int i = 0; i < TL::PA; ++i) dma16(asrc[i] + ks * BKB, adst + buf * TL::BUF_BYTES + 1024u * i);
   };
 
   // ---- fragment reads: lane l holds elements k = 8 (l >> 5) + j of row l & 31 -------------
@@ -158,7 +170,7 @@ __global__ __launch_bounds__(TL::WG, TL::OCC) void stem_gemm_kernel(stem::Gemm p
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
 
-  const int nk = K / BK;
+  const int nk = K * ES / BKB;
   // One K-step from LDS buffer `buf`: four sub-steps of 16.  Measured on this loop (64 clips,
   // 1.46 ms for both convolutions): without the LDS-DMA loads 1.09 ms, without the MFMAs 1.22 ms
   // - the two overlap only in part, and neither alone is near the matrix peak (0.5 ms).  What
@@ -172,18 +184,40 @@ __global__ __launch_bounds__(TL::WG, TL::OCC) void stem_gemm_kernel(stem::Gemm p
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       const int off = buf * TL::BUF_BYTES + (((2 * kk) ^ e) << 4);
-      h8 a[TL::RN], b[TL::RM];
+      if constexpr (F32) {
+        // the lane's 16 bytes are k = 4 (2 kk + half) + j, j = 0..3, of its row: MFMA j takes
+        // element j from both operands (a permutation of k, the same for both)
+        float4 a[TL::RN], b[TL::RM];
 #pragma unroll
-      for (int i = 0; i < TL::RN; ++i) a[i] = *reinterpret_cast<const h8*>(wbase + off + i * 32 * 128);
+        for (int i = 0; i < TL::RN; ++i) a[i] = *reinterpret_cast<const float4*>(wbase + off + i * 32 * 128);
 #pragma unroll
-      for (int i = 0; i < TL::RM; ++i) b[i] = *reinterpret_cast<const h8*>(abase + off + i * 32 * 128);
-      __builtin_amdgcn_s_setprio(1);
+        for (int i = 0; i < TL::RM; ++i) b[i] = *reinterpret_cast<const float4*>(abase + off + i * 32 * 128);
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-      for (int ni = 0; ni < TL::RN; ++ni)
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int mi = 0; mi < TL::RM; ++mi)
-          acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ni], b[mi], acc[ni][mi], 0, 0, 0);
-      __builtin_amdgcn_s_setprio(0);
+          for (int ni = 0; ni < TL::RN; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < TL::RM; ++mi) {
+              const float av = j == 0 ? a[ni].x : (j == 1 ? a[ni].y : (j == 2 ? a[ni].z : a[ni].w));
+              const float bv = j == 0 ? b[mi].x : (j == 1 ? b[mi].y : (j == 2 ? b[mi].z : b[mi].w));
+              acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[ni][mi], 0, 0, 0);
+            }
+        __builtin_amdgcn_s_setprio(0);
+      } else {
+        h8 a[TL::RN], b[TL::RM];
+#pragma unroll
+        for (int i = 0; i < TL::RN; ++i) a[i] = *reinterpret_cast<const h8*>(wbase + off + i * 32 * 128);
+#pragma unroll
+        for (int i = 0; i < TL::RM; ++i) b[i] = *reinterpret_cast<const h8*>(abase + off + i * 32 * 128);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ni = 0; ni < TL::RN; ++ni)
+#pragma unroll
+          for (int mi = 0; mi < TL::RM; ++mi)
+            acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ni], b[mi], acc[ni][mi], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+      }
     }
   };
   {
@@ -253,14 +287,14 @@ __global__ __launch_bounds__(TL::WG, TL::OCC) void stem_gemm_kernel(stem::Gemm p
   }
 }
 
-template <class TL, bool OUT_F16>
+template <class TL, class ET, bool OUT_F16>
 static int launch_stem_gemm(const stem::Gemm& g, hipStream_t s) {
   const long long tiles = ((long long)g.m_total + TL::BM - 1) / TL::BM * (g.n / TL::BN);
   if (tiles >= (1LL << 31)) {
     set_error("batch too large for one launch");
     return MIA_ERR_UNSUPPORTED;
   }
-  auto kern = stem_gemm_kernel<TL, OUT_F16>;
+  auto kern = stem_gemm_kernel<TL, ET, OUT_F16>;
   static bool attr_set = false;  // (per instantiation; the attribute is a property of the function)
   if (!attr_set) {
     MIA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -272,21 +306,23 @@ static int launch_stem_gemm(const stem::Gemm& g, hipStream_t s) {
 }
 // The 256 x 256 tile moves half the operand bytes per multiply-add; it needs enough tiles to
 // fill the chip and a channel count it divides.
-template <bool OUT_F16>
+template <class ET, bool OUT_F16>
 static int dispatch_stem_gemm(const stem::Gemm& g, int cus, hipStream_t s) {
   const long long tiles256 = ((long long)g.m_total + 255) / 256 * (g.n / 256);
-  if (g.n % 256 == 0 && tiles256 >= 2LL * cus) return launch_stem_gemm<StemTile256, OUT_F16>(g, s);
-  return launch_stem_gemm<StemTile128, OUT_F16>(g, s);
+  if (g.n % 256 == 0 && tiles256 >= 2LL * cus) return launch_stem_gemm<StemTile256, ET, OUT_F16>(g, s);
+  return launch_stem_gemm<StemTile128, ET, OUT_F16>(g, s);
 }
 
-// log-mel (clips, C, T) float32 -> (clips, T + 2, CP) float16, channels contiguous; rows 0 and
+// log-mel (clips, C, T) float32 -> (clips, T + 2, CP) of ET, channels contiguous; rows 0 and
 // T + 1 and channels >= C are zero.  grid (ceil((T + 2) / 64), clips): a workgroup writes rows
 // 64 bx .. 64 bx + 63 of the padded clip (frame = row - 1).
+template <class ET>
 __global__ __launch_bounds__(256) void stem_prep_kernel(const float* __restrict__ mel, int C, int T, int CP,
-                                                        _Float16* __restrict__ out) {
+                                                        ET* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char prep_raw[];
-  _Float16* tile = reinterpret_cast<_Float16*>(prep_raw);  // [64][CP + 8]
-  const int pitch = CP + 8;
+  ET* tile = reinterpret_cast<ET*>(prep_raw);  // [64][CP + 16 bytes]
+  constexpr int PER16 = 16 / (int)sizeof(ET);  // elements per 16-byte piece
+  const int pitch = CP + PER16;
   const long long clip = blockIdx.y;
   const int r0 = blockIdx.x * 64;
   const int tid = threadIdx.x, tl = tid & 63;
@@ -295,44 +331,105 @@ __global__ __launch_bounds__(256) void stem_prep_kernel(const float* __restrict_
   const float* __restrict__ src = mel + clip * (long long)C * T + (in ? frame : 0);
   for (int c = tid >> 6; c < CP; c += 4) {
     const float v = (in && c < C) ? src[(long long)c * T] : 0.0f;
-    tile[tl * pitch + c] = (_Float16)v;
+    tile[tl * pitch + c] = (ET)v;
   }
   __syncthreads();
-  const int pieces = CP / 8;  // 16-byte pieces per row
-  _Float16* __restrict__ dst = out + (clip * (long long)(T + 2) + r0) * CP;
+  const int pieces = CP / PER16;  // 16-byte pieces per row
+  ET* __restrict__ dst = out + (clip * (long long)(T + 2) + r0) * CP;
   for (int idx = tid; idx < 64 * pieces; idx += 256) {
     const int row = idx / pieces, cp = idx - row * pieces;
     if (r0 + row < T + 2) {
-      *reinterpret_cast<uint4*>(dst + (long long)row * CP + 8 * cp) =
-          *reinterpret_cast<const uint4*>(tile + row * pitch + 8 * cp);
+      *reinterpret_cast<uint4*>(dst + (long long)row * CP + PER16 * cp) =
+          *reinterpret_cast<const uint4*>(tile + row * pitch + PER16 * cp);
     }
   }
 }
 
-// rows 0 and rows - 1 of every clip of a (clips, rows, n) float16 array := 0
-__global__ __launch_bounds__(256) void stem_zero_rows_kernel(_Float16* __restrict__ x, long long rows, int n) {
+// rows 0 and rows - 1 of every clip of a (clips, rows, n) array := 0
+template <class ET>
+__global__ __launch_bounds__(256) void stem_zero_rows_kernel(ET* __restrict__ x, long long rows, int n) {
   const long long clip = blockIdx.y;
-  _Float16* __restrict__ a = x + clip * rows * n;
-  _Float16* __restrict__ b = a + (rows - 1) * n;
+  ET* __restrict__ a = x + clip * rows * n;
+  ET* __restrict__ b = a + (rows - 1) * n;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-    a[i] = (_Float16)0.0f;
-    b[i] = (_Float16)0.0f;
+    a[i] = (ET)0.0f;
+    b[i] = (ET)0.0f;
   }
 }
 
-// (n, 3, c) float32 -> (n, 3, cp) float16, zero-padded channels
+// (n, 3, c) float32 -> (n, 3, cp) of ET, zero-padded channels
+template <class ET>
 __global__ __launch_bounds__(256) void stem_pack_kernel(const float* __restrict__ w, long long rows, int c,
-                                                        int cp, _Float16* __restrict__ out) {
+                                                        int cp, ET* __restrict__ out) {
   const long long total = rows * cp;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const long long r = i / cp;
     const int ch = (int)(i - r * cp);
-    out[i] = ch < c ? (_Float16)w[r * c + ch] : (_Float16)0.0f;
+    out[i] = ch < c ? (ET)w[r * c + ch] : (ET)0.0f;
   }
 }
 
-static int stem_cpad(int c) { return (c + 63) / 64 * 64; }
+// channels padded to whole 128-byte K-steps
+static int stem_cpad(int c, size_t es) {
+  const int q = (int)(128 / es);
+  return (c + q - 1) / q * q;
+}
 static size_t stem_align(size_t x) { return (x + 255) & ~(size_t)255; }
+static bool stem_precision_ok(int precision) { return precision == MIA_STEM_F16 || precision == MIA_STEM_F32; }
+static size_t stem_es(int precision) { return precision == MIA_STEM_F32 ? 4 : 2; }
+
+template <class ET>
+static int stem_pack_t(const float* conv1_w, const float* conv2_w, int n_mels, int n_state, void* packed,
+                       hipStream_t s) {
+  const int cp = stem_cpad(n_mels, sizeof(ET));
+  ET* w1 = static_cast<ET*>(packed);
+  ET* w2 = reinterpret_cast<ET*>(static_cast<unsigned char*>(packed) +
+                                 stem_align((size_t)n_state * 3 * cp * sizeof(ET)));
+  hipLaunchKernelGGL(stem_pack_kernel<ET>, dim3(1024), dim3(256), 0, s, conv1_w, (long long)n_state * 3,
+                     n_mels, cp, w1);
+  hipLaunchKernelGGL(stem_pack_kernel<ET>, dim3(4096), dim3(256), 0, s, conv2_w, (long long)n_state * 3,
+                     n_state, n_state, w2);
+  MIA_CHECK_HIP(hipGetLastError());
+  return MIA_OK;
+}
+
+template <class ET>
+static int stem_run_t(const float* mel, int64_t clips, int64_t frames, int n_mels, int n_state,
+                      const void* packed, const float* conv1_b, const float* conv2_b, const float* pos,
+                      void* out, int out_f16, void* workspace, hipStream_t s) {
+  const int64_t t_out = (frames - 1) / 2 + 1;
+  const int cp = stem_cpad(n_mels, sizeof(ET));
+  const ET* w1 = static_cast<const ET*>(packed);
+  const ET* w2 = reinterpret_cast<const ET*>(static_cast<const unsigned char*>(packed) +
+                                             stem_align((size_t)n_state * 3 * cp * sizeof(ET)));
+  ET* x0 = static_cast<ET*>(workspace);
+  ET* h1 = reinterpret_cast<ET*>(static_cast<unsigned char*>(workspace) +
+                                 stem_align((size_t)clips * (frames + 2) * cp * sizeof(ET)));
+  constexpr int PER16 = 16 / (int)sizeof(ET);
+  const unsigned gy = 32768;  // clips per launch of the two small kernels (grid.y limit)
+  for (int64_t c0 = 0; c0 < clips; c0 += gy) {
+    const unsigned nc = (unsigned)(clips - c0 < gy ? clips - c0 : gy);
+    hipLaunchKernelGGL(stem_prep_kernel<ET>, dim3((unsigned)((frames + 2 + 63) / 64), nc), dim3(256),
+                       (size_t)64 * (cp + PER16) * sizeof(ET), s, mel + c0 * n_mels * frames, n_mels,
+                       (int)frames, cp, x0 + c0 * (frames + 2) * cp);
+    hipLaunchKernelGGL(stem_zero_rows_kernel<ET>, dim3(2, nc), dim3(256), 0, s,
+                       h1 + c0 * (frames + 2) * n_state, (long long)(frames + 2), n_state);
+  }
+  int dev = 0, cus = 256;
+  MIA_CHECK_HIP(hipGetDevice(&dev));
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  constexpr bool H1_F16 = sizeof(ET) == 2;  // the intermediate has the operands' type
+  stem::Gemm g1{x0, frames + 2, cp, 1, (int)frames, (int)(clips * frames), w1, conv1_b, nullptr, n_state,
+                h1, frames + 2, 1};
+  int rc = dispatch_stem_gemm<ET, H1_F16>(g1, cus, s);
+  if (rc != MIA_OK) return rc;
+  stem::Gemm g2{h1, frames + 2, n_state, 2, (int)t_out, (int)(clips * t_out), w2, conv2_b, pos, n_state,
+                out, t_out, 0};
+  rc = out_f16 ? dispatch_stem_gemm<ET, true>(g2, cus, s) : dispatch_stem_gemm<ET, false>(g2, cus, s);
+  if (rc != MIA_OK) return rc;
+  MIA_CHECK_HIP(hipGetLastError());
+  return MIA_OK;
+}
 
 }  // namespace mia
 
@@ -340,46 +437,44 @@ using namespace mia;
 
 extern "C" {
 
-size_t mia_whisper_stem_weight_bytes(int n_mels, int n_state) {
-  if (n_mels <= 0 || n_state <= 0) return 0;
-  return stem_align((size_t)n_state * 3 * stem_cpad(n_mels) * 2) + stem_align((size_t)n_state * 3 * n_state * 2);
+size_t mia_whisper_stem_weight_bytes(int n_mels, int n_state, int precision) {
+  if (n_mels <= 0 || n_state <= 0 || !stem_precision_ok(precision)) return 0;
+  const size_t es = stem_es(precision);
+  return stem_align((size_t)n_state * 3 * stem_cpad(n_mels, es) * es) +
+         stem_align((size_t)n_state * 3 * n_state * es);
 }
 
-int mia_whisper_stem_pack(const float* conv1_w, const float* conv2_w, int n_mels, int n_state, void* packed,
-                          void* stream) {
+int mia_whisper_stem_pack(const float* conv1_w, const float* conv2_w, int n_mels, int n_state,
+                          int precision, void* packed, void* stream) {
   MIA_REQUIRE(conv1_w && conv2_w && packed, "null argument");
+  MIA_REQUIRE(stem_precision_ok(precision), "unknown precision %d", precision);
   MIA_REQUIRE(n_mels > 0 && n_state > 0 && n_state % 128 == 0,
               "n_state must be a positive multiple of 128 (got %d)", n_state);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const int cp = stem_cpad(n_mels);
-  _Float16* w1 = static_cast<_Float16*>(packed);
-  _Float16* w2 = reinterpret_cast<_Float16*>(static_cast<unsigned char*>(packed) +
-                                             stem_align((size_t)n_state * 3 * cp * 2));
-  hipLaunchKernelGGL(stem_pack_kernel, dim3(1024), dim3(256), 0, s, conv1_w, (long long)n_state * 3, n_mels,
-                     cp, w1);
-  hipLaunchKernelGGL(stem_pack_kernel, dim3(4096), dim3(256), 0, s, conv2_w, (long long)n_state * 3, n_state,
-                     n_state, w2);
-  MIA_CHECK_HIP(hipGetLastError());
-  return MIA_OK;
+  return precision == MIA_STEM_F32 ? stem_pack_t<float>(conv1_w, conv2_w, n_mels, n_state, packed, s)
+                                   : stem_pack_t<_Float16>(conv1_w, conv2_w, n_mels, n_state, packed, s);
 }
 
-size_t mia_whisper_stem_workspace_bytes(int64_t clips, int64_t frames, int n_mels, int n_state) {
-  if (clips <= 0 || frames <= 0 || n_mels <= 0 || n_state <= 0) return 0;
-  return stem_align((size_t)clips * (frames + 2) * stem_cpad(n_mels) * 2) +
-         stem_align((size_t)clips * (frames + 2) * n_state * 2);
+size_t mia_whisper_stem_workspace_bytes(int64_t clips, int64_t frames, int n_mels, int n_state,
+                                        int precision) {
+  if (clips <= 0 || frames <= 0 || n_mels <= 0 || n_state <= 0 || !stem_precision_ok(precision)) return 0;
+  const size_t es = stem_es(precision);
+  return stem_align((size_t)clips * (frames + 2) * stem_cpad(n_mels, es) * es) +
+         stem_align((size_t)clips * (frames + 2) * n_state * es);
 }
 
 int mia_whisper_stem(const float* mel, int64_t clips, int64_t frames, int n_mels, int n_state,
-                     const void* packed, const float* conv1_b, const float* conv2_b, const float* pos,
-                     void* out, int out_f16, void* workspace, size_t workspace_bytes, void* stream) {
+                     int precision, const void* packed, const float* conv1_b, const float* conv2_b,
+                     const float* pos, void* out, int out_f16, void* workspace, size_t workspace_bytes,
+                     void* stream) {
   MIA_REQUIRE(clips >= 0 && frames > 0, "bad shape");
+  MIA_REQUIRE(stem_precision_ok(precision), "unknown precision %d", precision);
   if (clips == 0) return MIA_OK;
   MIA_REQUIRE(mel && packed && conv1_b && conv2_b && out && workspace, "null argument");
   MIA_REQUIRE(n_mels > 0 && n_state > 0 && n_state % 128 == 0,
               "n_state must be a positive multiple of 128 (got %d)", n_state);
-  MIA_REQUIRE(workspace_bytes >= mia_whisper_stem_workspace_bytes(clips, frames, n_mels, n_state),
+  MIA_REQUIRE(workspace_bytes >= mia_whisper_stem_workspace_bytes(clips, frames, n_mels, n_state, precision),
               "workspace too small");
-  const int64_t t_out = (frames - 1) / 2 + 1;
   MIA_REQUIRE(clips * frames < (1LL << 31) - 256, "batch too large for one call: %lld frames (split the batch)",
               (long long)(clips * frames));
   MIA_REQUIRE((reinterpret_cast<uintptr_t>(packed) & 15) == 0 && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0 &&
@@ -387,35 +482,12 @@ int mia_whisper_stem(const float* mel, int64_t clips, int64_t frames, int n_mels
                   (reinterpret_cast<uintptr_t>(conv2_b) & 15) == 0 && (reinterpret_cast<uintptr_t>(pos) & 15) == 0,
               "pointers must be 16-byte aligned");
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const int cp = stem_cpad(n_mels);
-  const _Float16* w1 = static_cast<const _Float16*>(packed);
-  const _Float16* w2 = reinterpret_cast<const _Float16*>(static_cast<const unsigned char*>(packed) +
-                                                         stem_align((size_t)n_state * 3 * cp * 2));
-  _Float16* x0 = static_cast<_Float16*>(workspace);
-  _Float16* h1 = reinterpret_cast<_Float16*>(static_cast<unsigned char*>(workspace) +
-                                             stem_align((size_t)clips * (frames + 2) * cp * 2));
-  const unsigned gy = 32768;  // clips per launch of the two small kernels (grid.y limit)
-  for (int64_t c0 = 0; c0 < clips; c0 += gy) {
-    const unsigned nc = (unsigned)(clips - c0 < gy ? clips - c0 : gy);
-    hipLaunchKernelGGL(stem_prep_kernel, dim3((unsigned)((frames + 2 + 63) / 64), nc), dim3(256),
-                       (size_t)64 * (cp + 8) * 2, s, mel + c0 * n_mels * frames, n_mels, (int)frames, cp,
-                       x0 + c0 * (frames + 2) * cp);
-    hipLaunchKernelGGL(stem_zero_rows_kernel, dim3(2, nc), dim3(256), 0, s, h1 + c0 * (frames + 2) * n_state,
-                       (long long)(frames + 2), n_state);
+  if (precision == MIA_STEM_F32) {
+    return stem_run_t<float>(mel, clips, frames, n_mels, n_state, packed, conv1_b, conv2_b, pos, out,
+                             out_f16, workspace, s);
   }
-  int dev = 0, cus = 256;
-  MIA_CHECK_HIP(hipGetDevice(&dev));
-  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-  stem::Gemm g1{x0, frames + 2, cp, 1, (int)frames, (int)(clips * frames), w1, conv1_b, nullptr, n_state,
-                h1, frames + 2, 1};
-  int rc = dispatch_stem_gemm<true>(g1, cus, s);
-  if (rc != MIA_OK) return rc;
-  stem::Gemm g2{h1, frames + 2, n_state, 2, (int)t_out, (int)(clips * t_out), w2, conv2_b, pos, n_state,
-                out, t_out, 0};
-  rc = out_f16 ? dispatch_stem_gemm<true>(g2, cus, s) : dispatch_stem_gemm<false>(g2, cus, s);
-  if (rc != MIA_OK) return rc;
-  MIA_CHECK_HIP(hipGetLastError());
-  return MIA_OK;
+  return stem_run_t<_Float16>(mel, clips, frames, n_mels, n_state, packed, conv1_b, conv2_b, pos, out,
+                              out_f16, workspace, s);
 }
 
 }  // extern "C"

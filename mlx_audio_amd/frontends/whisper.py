@@ -70,11 +70,29 @@ class WhisperEncoderStem:
     + positional_embedding[:frames'].
 
     Weights come in the reference's layout, (out_channels, kernel, in_channels), biases
-    (out_channels,).  They are rounded to float16 once, here; the products run on the matrix
-    cores with float32 accumulation, bias / GELU (exact, erf form) / embedding in float32.
+    (out_channels,).  `precision` chooses the arithmetic of the convolutions:
+
+    * "f32": weights, spectrogram and the intermediate stay float32 and the products run on the
+      float32 matrix instruction (a chain of fused multiply-adds in float32) - what the
+      reference's `nn.Conv1d` computes on a float32 checkpoint;
+    * "f16": weights, spectrogram and the conv1 -> GELU intermediate are rounded to float16,
+      accumulation in float32 - the precision of a float16 checkpoint, at 16 x the rate;
+    * None (default): "f16" when the weights arrive as float16 tensors, "f32" otherwise, so a
+      float32 checkpoint is never narrowed without the caller asking for it.
+
+    Bias, GELU (exact, erf form) and the embedding are float32 either way.
     """
 
-    def __init__(self, conv1_weight, conv1_bias, conv2_weight, conv2_bias, positional_embedding=None):
+    def __init__(self, conv1_weight, conv1_bias, conv2_weight, conv2_bias, positional_embedding=None,
+                 precision=None):
+        if precision is None:
+            dts = [getattr(w, "dtype", None) for w in (conv1_weight, conv2_weight)]
+            half = all(str(d) in ("torch.float16", "float16") for d in dts)
+            precision = "f16" if half else "f32"
+        if precision not in ("f16", "f32"):
+            raise ValueError(f"precision must be 'f16', 'f32' or None, got {precision!r}")
+        self.precision = precision
+        self._pcode = _lib.STEM_F16 if precision == "f16" else _lib.STEM_F32
         w1 = as_device_f32(conv1_weight, ndim_allowed=(3,))
         w2 = as_device_f32(conv2_weight, ndim_allowed=(3,))
         n_state, k1, n_mels = w1.shape
@@ -96,16 +114,19 @@ class WhisperEncoderStem:
                 raise ValueError("positional_embedding must be (n_ctx, n_state)")
             self.pos = pos
         lib = _lib.lib()
-        nbytes = lib.mia_whisper_stem_weight_bytes(self.n_mels, self.n_state)
+        nbytes = lib.mia_whisper_stem_weight_bytes(self.n_mels, self.n_state, self._pcode)
         self.packed = torch.empty((nbytes,), dtype=torch.uint8, device=self.device)
         with torch.cuda.device(self.device):
             _lib.check(lib.mia_whisper_stem_pack(w1.data_ptr(), w2.data_ptr(), self.n_mels, self.n_state,
-                                                 self.packed.data_ptr(),
+                                                 self._pcode, self.packed.data_ptr(),
                                                  torch.cuda.current_stream(self.device).cuda_stream))
         self._ws = None
 
-    def __call__(self, mel, out_dtype=torch.float16) -> torch.Tensor:
-        """mel [B, n_mels, T] or [n_mels, T] -> [B, (T - 1) // 2 + 1, n_state]."""
+    def __call__(self, mel, out_dtype=None) -> torch.Tensor:
+        """mel [B, n_mels, T] or [n_mels, T] -> [B, (T - 1) // 2 + 1, n_state]; out_dtype
+        defaults to the precision's own type (float32 for "f32", float16 for "f16")."""
+        if out_dtype is None:
+            out_dtype = torch.float32 if self.precision == "f32" else torch.float16
         x = as_device_f32(mel, ndim_allowed=(2, 3)).to(self.device)
         if x.dim() == 2:
             x = x[None]
@@ -125,7 +146,7 @@ class WhisperEncoderStem:
             return out
         # clips per call: the kernel indexes frames with 32 bits
         per_call = max(1, min(B, ((1 << 31) - 512) // T))
-        need = lib.mia_whisper_stem_workspace_bytes(per_call, T, self.n_mels, self.n_state)
+        need = lib.mia_whisper_stem_workspace_bytes(per_call, T, self.n_mels, self.n_state, self._pcode)
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty((need,), dtype=torch.uint8, device=self.device)
         with torch.cuda.device(self.device):
@@ -133,7 +154,8 @@ class WhisperEncoderStem:
             for b0 in range(0, B, per_call):
                 nb = min(per_call, B - b0)
                 _lib.check(lib.mia_whisper_stem(
-                    x[b0:b0 + nb].data_ptr(), nb, T, self.n_mels, self.n_state, self.packed.data_ptr(),
+                    x[b0:b0 + nb].data_ptr(), nb, T, self.n_mels, self.n_state, self._pcode,
+                    self.packed.data_ptr(),
                     self.bias1.data_ptr(), self.bias2.data_ptr(),
                     self.pos.data_ptr() if self.pos is not None else None,
                     out[b0:b0 + nb].data_ptr(), 1 if out_dtype == torch.float16 else 0,
@@ -142,7 +164,7 @@ class WhisperEncoderStem:
 
 
 def whisper_encoder_stem(mel, conv1_weight, conv1_bias, conv2_weight, conv2_bias, positional_embedding=None,
-                         out_dtype=torch.float16) -> torch.Tensor:
+                         out_dtype=None, precision=None) -> torch.Tensor:
     """One-shot form of `WhisperEncoderStem` (packs the weights on every call)."""
-    return WhisperEncoderStem(conv1_weight, conv1_bias, conv2_weight, conv2_bias, positional_embedding)(
-        mel, out_dtype=out_dtype)
+    return WhisperEncoderStem(conv1_weight, conv1_bias, conv2_weight, conv2_bias, positional_embedding,
+                              precision=precision)(mel, out_dtype=out_dtype)

@@ -34,6 +34,7 @@ WORKLOAD_SOURCES = {
     "spectral_gate": ["gate.hip", "spectral_fwd.hip", "spectral_inv.hip", "ops.hip"] + _COMMON,
     "demucs_front": ["normalize.hip", "spectral_fwd.hip", "ops.hip"] + _COMMON,
     "whisper_stem": ["stem.hip"],
+    "whisper_stem_f16": ["stem.hip"],
 }
 
 
