@@ -115,6 +115,10 @@ def _fft_tables(lib, n_in: int, n_out: int, dev: torch.device, work: torch.Tenso
             _fft_tables_cache.move_to_end(key)
             tables, ready = hit
             cur.wait_event(ready)
+            # The block belongs to the allocator pool of the stream that built it: tell the
+            # allocator that this stream reads it too, or an evicted entry could be handed out
+            # again while kernels queued here still read it.
+            tables.record_stream(cur)
             return tables
         tables = torch.empty(lib.mia_resample_fft_table_bytes(n_in, n_out), dtype=torch.uint8,
                              device=dev)

@@ -409,3 +409,33 @@ def test_fourier_tables_built_on_one_stream_are_safe_on_another(gpu):
     for got in (ya, yb):
         assert np.abs(got.cpu().numpy() - want).max() <= 2e-6 * peak
     assert torch.equal(ya, yb)
+
+
+def test_fourier_tables_evicted_while_another_stream_still_reads_them(gpu):
+    """The table cache keeps eight entries.  A stream that got its tables by a cache hit may
+    still have kernels queued on them when later calls (on the building stream) evict the
+    entry and the allocator reuses the block: the hit registers its stream with the block, so
+    the reuse waits.  The queued call's result must be what a quiet run gives."""
+    import importlib
+
+    rs = importlib.import_module("mlx_audio_amd.primitives.resample")
+    rng = np.random.default_rng(32)
+    n, sr_out = 30011, 11003
+    x = rng.standard_normal((3, n)).astype(np.float32)
+    xd = torch.from_numpy(x).to(gpu)
+    with rs._fft_tables_lock:
+        rs._fft_tables_cache.clear()
+    quiet = resample(xd, n, sr_out).clone()
+    torch.cuda.synchronize()
+    b = torch.cuda.Stream()
+    with torch.cuda.stream(b):
+        junk = torch.randn((1 << 26,), device=gpu)
+        for _ in range(20):
+            junk = junk * 1.0001 + 0.5
+        yb = resample(xd, n, sr_out)          # cache hit on b, queued behind the junk
+    # meanwhile, on the building stream: nine other lengths evict the entry and allocate anew
+    others = [resample(xd[:, :n - 2 * k], n - 2 * k, sr_out) for k in range(1, 10)]
+    assert (n, quiet.shape[-1], xd.device.index) not in rs._fft_tables_cache
+    torch.cuda.synchronize()
+    assert torch.equal(yb, quiet)
+    assert all(torch.isfinite(o).all() for o in others)

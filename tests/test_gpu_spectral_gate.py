@@ -193,6 +193,27 @@ def test_spectral_gate_matches_the_oracle(gpu, kw):
     assert np.abs(one - orc.spectral_gate(y[0], **kw)).max() <= 2e-4 * np.abs(want).max()
 
 
+@pytest.mark.parametrize("kw", [{}, {"freq_smooth_hz": 4000.0}])   # direct (spectrum rows) / magnitude plane
+def test_quiet_frame_choice_with_ties(gpu, kw):
+    """Runs of digital silence and repeated stretches give frames with exactly equal energy, so
+    which of them count as "the quietest tenth" depends on how ties are broken (the reference:
+    NumPy's argsort on the host; here a stable device sort, on energies summed in another
+    order).  Tied frames of this kind are equal frames, so the noise statistics - and with them
+    the output - must not depend on the choice: both branches against the oracle."""
+    rng = np.random.default_rng(5)
+    n = 22050 * 2
+    y = np.zeros((2, n), np.float32)
+    burst = (0.3 * rng.standard_normal(4096)).astype(np.float32)
+    for start in (6000, 14192, 22384):            # the same burst three times: tied loud frames
+        y[0, start:start + 4096] = burst
+    y[0, 32000:] = (0.01 * rng.standard_normal(n - 32000)).astype(np.float32)
+    y[1, :] = np.tile((0.05 * rng.standard_normal(2048)).astype(np.float32), n // 2048 + 1)[:n]  # periodic: every frame ties
+    y[1, 20000:24000] = 0.0
+    got = spectral_gate(_dev(y, gpu), **kw).cpu().numpy()
+    want = orc.spectral_gate(y, **kw)
+    assert np.abs(got - want).max() <= 2e-4 * max(np.abs(want).max(), 1e-3)
+
+
 def test_noise_profile_and_adaptive(gpu):
     y = _noisy()
     for prof in (y[0, :4000], y[:, :4000]):
