@@ -567,6 +567,10 @@ int mia_plan_set_option(mia_plan* plan, const char* key, int value) {
     plan->opt_dpp_pass2 = value != 0;
     return MIA_OK;
   }
+  if (strcmp(key, "fwd_lane") == 0) {
+    plan->opt_lane = value != 0;
+    return MIA_OK;
+  }
   set_error("unknown plan option '%s'", key);
   return MIA_ERR_INVALID;
 }
@@ -629,6 +633,9 @@ static int fill_fwd(const mia_plan* plan, const float* y, int64_t B, int64_t T, 
   p.win = plan->d_window;
   p.tw = plan->d_tw;
   p.scale = 1.0f;
+#ifdef MIA_DEBUG_HOOKS
+  { const char* e = getenv("MIA_DBG"); p.dbg = e ? atoi(e) : 0; }  // profiling builds only
+#endif
   return MIA_OK;
 }
 

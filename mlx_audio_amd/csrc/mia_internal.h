@@ -107,6 +107,8 @@ struct mia_plan {
   int opt_vgpr_staging = 0;      // mia_plan_set_option("w400_vgpr_staging"): ablation / test knob
   int opt_mfma_mel = 0;          // mia_plan_set_option("w400_mfma_mel"): A/B knob, matrix-core projection
   int opt_dpp_pass2 = 0;         // mia_plan_set_option("w400_dpp_pass2"): A/B knob, cross-lane (DPP) radix-16 pass
+  int opt_lane = 0;              // mia_plan_set_option("fwd_lane"): A/B knob, frame-major mel rows at n_fft 1024 by
+                                 // the wave-private kernel of spectral_lane.hip
   int* d_mfma_meta = nullptr;    // tables of that projection (n_mels <= 128)
   float* d_mfma_a = nullptr;
 };
@@ -220,6 +222,8 @@ int launch_inverse_generic(const mia_plan* plan, const InvParams& p, void* works
                            size_t workspace_bytes, hipStream_t s);
 int forward_tile_frames(int n_fft, int mode);
 bool forward_frame_major_ok(int n_fft, int n_mels);
+bool forward_lane_ok(int n_fft, int hop, int n_mels, int nnz);
+int launch_forward_lane(const FwdParams& p, int cus, hipStream_t s);
 bool dct2_frame_major_ok(int n_in, int n_out);
 int launch_dct2_frame_major(const float* x, long long outer, int n_in, long long inner, const float* basis,
                             int n_out, float* out, const int* keys, long long key_stride, float top,

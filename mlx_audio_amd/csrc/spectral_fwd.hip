@@ -478,6 +478,20 @@ __global__ __launch_bounds__(WG, C::OCC) void fwd_kernel(FwdParams p) {
       const float half_scale = 0.5f * p.scale;
       auto emit = [&](int k, float2 X) {
         if constexpr (MODE == 0) {
+#ifdef MIA_DEBUG_HOOKS  // ablations (garbage results): bit 4 no stores, bit 32 every row to the first frame's row (L2-resident)
+          if (p.dbg & 4) {
+            asm volatile("" ::"v"(X.x), "v"(X.y));
+            return;
+          }
+          if (p.dbg & 64) {  // rows at a 128-byte-aligned pitch (2048 bins, the last one dropped)
+            if (k < M) p.cout[(b * p.F + f) * (long long)M + k] = {X.x * half_scale, X.y * half_scale};
+            return;
+          }
+          if (p.dbg & 32) {
+            p.cout[(blockIdx.x & 1023) * (long long)(M + 1) + k] = {X.x * half_scale, X.y * half_scale};
+            return;
+          }
+#endif
           crow[k] = {X.x * half_scale, X.y * half_scale};
         } else if constexpr (MODE == 5) {
           const float2 z = {X.x * half_scale, X.y * half_scale};
@@ -901,6 +915,12 @@ int forward_tile_frames(int n_fft, int /*mode*/) {
 }
 
 int launch_forward(const mia_plan* plan, const FwdParams& p, int mode, hipStream_t s) {
+  // frame-major mel rows at n_fft 1024 by the wave-private kernel (spectral_lane.hip): an A/B
+  // option - on the CLAP workload it equals the four-pass kernel's time, see the profiles
+  if (mode == 1 && p.frame_major && plan->opt_lane &&
+      forward_lane_ok(plan->n_fft, plan->hop, p.n_mels, p.nnz)) {
+    return launch_forward_lane(p, plan->cus, s);
+  }
   if (mode == 0) return dispatch_mode<0>(plan->n_fft, p, s);
   if (mode == 5) return dispatch_mode<5>(plan->n_fft, p, s);
   if (mode == 1) return p.frame_major ? dispatch_mode<3>(plan->n_fft, p, s) : dispatch_mode<1>(plan->n_fft, p, s);

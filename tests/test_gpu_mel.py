@@ -323,3 +323,45 @@ def test_frame_major_mel_unsupported_plans(gpu):
     c = _mel_raw(y, 16000, 1024, 256, None, "hann", True, "constant", 2.0, 30, 0.0, None, False, "slaney",
                  frames_first=True)
     assert c.shape[2] == 30 and not c.is_contiguous()
+
+
+@pytest.mark.parametrize("hop,n_mels,pad_mode,served", [
+    (480, 64, "reflect", True), (256, 128, "constant", True), (384, 80, "edge", True), (170, 32, "reflect", True),
+    (512, 80, "edge", False),      # four frames' samples per wave no longer fit the LDS beside the exchange rows
+    (480, 40, "reflect", False)])  # bands in sixteens only
+def test_wave_private_kernel_option(gpu, hop, n_mels, pad_mode, served):
+    """Plan option "fwd_lane": frame-major mel rows at n_fft 1024 from the kernel in which four
+    frames share a wave (16 lanes each, radix 32 x 16 with one exchange) instead of the four-pass
+    kernel.  Another order of additions, so float32 round-off apart from the default path; both
+    against the float64 oracle as well.  Edge frames, a ragged frame count and a quiet stretch;
+    plans outside the kernel's limits keep the default path."""
+    from mlx_audio_amd import _lib
+    from mlx_audio_amd._runtime import get_plan
+    from mlx_audio_amd.primitives.mel import _mel_raw, mel_filterbank_np, padded_window_np
+
+    g = torch.Generator(device="cuda").manual_seed(hop + n_mels)
+    y = torch.randn((3, 7 * 1024 + 333), device=gpu, generator=g)
+    y[1, :3000] *= 1e-3
+    args = (y, 16000, 1024, hop, None, "hann", True, pad_mode, 2.0, n_mels, 0.0, None, False, "slaney")
+    plan = get_plan(y.device, 1024, hop, True, pad_mode, padded_window_np("hann", 1024, 1024),
+                    mel_basis=mel_filterbank_np(16000, 1024, n_mels, 0.0, None, False, "slaney"), power=2.0)
+    lib = _lib.lib()
+    for kw in ({}, {"epilogue": _lib.EPI_DB, "top_db": 80.0, "per_clip": True}):
+        want = _mel_raw(*args, frames_first=True, **kw)
+        try:
+            _lib.check(lib.mia_plan_set_option(plan.handle, b"fwd_lane", 1))
+            got = _mel_raw(*args, frames_first=True, **kw)
+        finally:
+            lib.mia_plan_set_option(plan.handle, b"fwd_lane", 0)
+        assert got.shape == want.shape and got.is_contiguous()
+        if not served:  # plans the kernel does not serve stay on the four-pass kernel
+            assert torch.equal(got, want)
+            continue
+        assert not torch.equal(got, want)  # the option did switch kernels
+        if kw:
+            assert (got - want).abs().max().item() <= 2e-4  # dB
+        else:
+            ref = o.melspectrogram(y.cpu().numpy(), sr=16000, n_fft=1024, hop_length=hop, n_mels=n_mels,
+                                   pad_mode=pad_mode).transpose(0, 2, 1)
+            np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=1e-4, atol=1e-5 * ref.max())
+            np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=2e-5, atol=1e-6 * ref.max())
