@@ -9,9 +9,9 @@ mkdir -p "$out"
 export TMPDIR=/tmp
 cd /tmp
 timeout -s KILL 120 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d "$out/a" -- \
-  python3 "$root/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > "$out/a.log" 2>&1 || exit 1
+  python3 "$root/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-secondary > "$out/a.log" 2>&1 || exit 1
 timeout -s KILL 120 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT --output-format csv -d "$out/b" -- \
-  python3 "$root/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > "$out/b.log" 2>&1 || exit 1
+  python3 "$root/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-secondary > "$out/b.log" 2>&1 || exit 1
 cd "$root"
 python3 - "$out" <<'PY'
 import csv, glob, sys
