@@ -10,9 +10,12 @@ array library, MLX, is absent) and its tests hold tolerances and recipes but no
 stored numbers for this path.  The oracle is therefore pinned only by
   * independent implementations available offline (CPU torch.stft/istft,
     scipy.signal.get_window, scipy.fft.dct, transformers.audio_utils),
+  * the whole Whisper and CLAP feature chains as Hugging Face transformers
+    computes them (the code behind WhisperFeatureExtractor / ClapFeatureExtractor;
+    tests/golden/hf_features_golden.npz, tests/test_golden.py),
   * the analytic known-answer cases the reference's own tests use, and
   * the reference's published tolerances,
-all exercised in tests/test_oracle_*.py.
+all exercised in tests/test_oracle_*.py and tests/test_golden.py.
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
 this package; the product path (mlx_audio_amd) never does.

@@ -111,3 +111,82 @@ def test_hip_mfcc_golden(gpu):
     got = mfcc(x, sr=16000, n_mfcc=13, n_fft=512, hop_length=128, n_mels=40, fmax=8000.0,
                per_clip=True).cpu().numpy()
     np.testing.assert_allclose(got, G["mfcc_512_40_13"], rtol=1e-4, atol=5e-3)
+
+
+# ------------------------------------------------- whole chains from Hugging Face's feature code
+# tests/golden/hf_features_golden.npz (make_golden_hf.py): transformers.audio_utils.spectrogram /
+# mel_filter_bank / window_function - the routines behind WhisperFeatureExtractor and
+# ClapFeatureExtractor - in float64, on a speech-like clip with a quiet stretch, ragged noise
+# and a chirp.  OpenAI's Whisper front end pads by reflection where the reference pads with
+# zeros (primitives/stft.py:143), so the Whisper vectors pin the chain with pad_mode="reflect".
+
+H = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden",
+                         "hf_features_golden.npz"), allow_pickle=False)
+
+
+def _whisper_epilogue_without_last_frame(mel):
+    ls = np.log10(np.maximum(np.asarray(mel, dtype=np.float64), 1e-10))[..., :-1]
+    return (np.maximum(ls, ls.max() - 8.0) + 4.0) / 4.0
+
+
+@pytest.mark.parametrize("n_mels", [80, 128])
+@pytest.mark.parametrize("clip", ["a", "b"])
+def test_oracle_whisper_chain_against_hf(n_mels, clip):
+    y = H[f"whisper_in_{clip}"]
+    want = H[f"whisper{n_mels}_{clip}"]
+    for dtype, tol in ((np.float64, 5e-6), (np.float32, 2e-5)):
+        mel = o.melspectrogram(y, sr=16000, n_fft=400, hop_length=160, n_mels=n_mels, fmin=0.0,
+                               fmax=8000.0, pad_mode="reflect", dtype=dtype)
+        got = _whisper_epilogue_without_last_frame(mel)
+        assert got.shape == want.shape
+        assert np.abs(got - want).max() <= tol, (n_mels, clip, dtype)
+    # interior frames do not see the padding: the reference's own (zero-padded) form agrees there
+    own = o.compute_log_mel_spectrogram(y, n_mels=n_mels)[:, 2:want.shape[1] - 2]
+    ref = want[:, 2:-2]
+    clear = (own > own.min() + 1e-3) & (ref > ref.min() + 1e-3)  # above both floors
+    assert clear.mean() > 0.5 and np.abs(own - ref)[clear].max() <= 2e-5
+
+
+def test_oracle_clap_chain_against_hf():
+    want = H["clap64"]
+    for dtype, tol in ((np.float64, 2e-4), (np.float32, 5e-4)):  # dB
+        got = np.asarray(o.clap_mel(H["clap_in"], dtype=dtype))
+        assert got.shape == want.shape == (101, 64)
+        assert np.abs(got - want).max() <= tol, dtype
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_mels", [80, 128])
+@pytest.mark.parametrize("clip", ["a", "b"])
+def test_hip_whisper_chain_against_hf(gpu, n_mels, clip):
+    """The n_fft = 400 / hop 160 kernel (reflect padding) against Hugging Face's Whisper features:
+    its mel powers with the epilogue applied here, and its own fused log epilogue wherever the
+    clip's maximum - which the kernel takes over all frames, OpenAI over all but the last - is the
+    same."""
+    import torch
+
+    from mlx_audio_amd import _lib
+    from mlx_audio_amd.primitives.mel import _mel_raw
+
+    y = torch.from_numpy(H[f"whisper_in_{clip}"]).to(gpu)[None]
+    want = H[f"whisper{n_mels}_{clip}"]
+    args = (y, 16000, 400, 160, None, "hann", True, "reflect", 2.0, n_mels, 0.0, 8000.0, False, "slaney")
+    mel = _mel_raw(*args).cpu().numpy()[0]
+    assert np.abs(_whisper_epilogue_without_last_frame(mel) - want).max() <= 2e-5
+    fused = _mel_raw(*args, epilogue=_lib.EPI_WHISPER, per_clip=True).cpu().numpy()[0]
+    if fused.max() == fused[:, :-1].max():
+        assert np.abs(fused[:, :-1] - want).max() <= 2e-5
+    else:
+        clear = want > want.min() + 1e-3
+        assert np.abs(fused[:, :-1] - want)[clear].max() <= 2e-5
+
+
+@pytest.mark.gpu
+def test_hip_clap_chain_against_hf(gpu):
+    import torch
+
+    from mlx_audio_amd.frontends import clap_log_mel
+
+    got = clap_log_mel(torch.from_numpy(H["clap_in"]).to(gpu)).cpu().numpy()
+    assert got.shape == (101, 64)
+    assert np.abs(got - H["clap64"]).max() <= 2e-3  # dB

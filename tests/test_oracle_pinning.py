@@ -410,3 +410,21 @@ def test_clap_fusion_structure():
     short = rng.standard_normal(480000).astype(np.float32)
     stack2, _ = o.clap_fusion_mel(short, np.random.default_rng(0))
     assert np.array_equal(stack2[0], stack2[3]) and stack2.shape == (4, 1001, 64)
+
+
+@pytest.mark.parametrize("n_mels", [80, 128])
+def test_whisper_chain_against_the_transformers_extractor(n_mels):
+    """WhisperFeatureExtractor itself (the object applications use) on a 30 s clip: OpenAI's
+    front end = reflect padding, last frame dropped; the rest of the chain is the reference's."""
+    transformers = pytest.importorskip("transformers")
+    rng = np.random.default_rng(5)
+    y = (0.1 * rng.standard_normal(480000)).astype(np.float32)
+    y[:100000] *= 1e-3
+    fe = transformers.WhisperFeatureExtractor(feature_size=n_mels)
+    want = fe(y, sampling_rate=16000, return_tensors="np")["input_features"][0]
+    mel = o.melspectrogram(y, sr=16000, n_fft=400, hop_length=160, n_mels=n_mels, fmin=0.0, fmax=8000.0,
+                           pad_mode="reflect", dtype=np.float64)
+    ls = np.log10(np.maximum(mel, 1e-10))[:, :-1]
+    got = (np.maximum(ls, ls.max() - 8.0) + 4.0) / 4.0
+    assert got.shape == want.shape == (n_mels, 3000)
+    assert np.abs(got - want).max() <= 1e-4  # the extractor computes in float32
