@@ -87,6 +87,20 @@ struct FftCfg {
   }
 };
 
+// One bin of the spectrum to memory.  Plans whose waves store whole 512-byte runs (a frame over
+// one or more whole waves) mark the rows nontemporal: they are not read again by the launch, and
+// the samples that neighbouring frames share stay in the L2 (HTDemucs round trip 11.34 -> 11.12 ms,
+// 2048-point stft -5 %); the small plans' short runs lose by it (800 points +58 %).
+typedef float fwd_f2 __attribute__((ext_vector_type(2)));
+template <bool STREAM>
+__device__ __forceinline__ void store_bin(float2* dst, float2 v) {
+  if constexpr (STREAM) {
+    __builtin_nontemporal_store(fwd_f2{v.x, v.y}, reinterpret_cast<fwd_f2*>(dst));
+  } else {
+    *dst = v;
+  }
+}
+
 template <class C>
 __device__ __forceinline__ void group_sync() {
   if constexpr (C::MULTIWAVE) {
@@ -492,10 +506,10 @@ __global__ __launch_bounds__(WG, C::OCC) void fwd_kernel(FwdParams p) {
             return;
           }
 #endif
-          crow[k] = {X.x * half_scale, X.y * half_scale};
+          store_bin<(C::N >= 2048)>(crow + k, {X.x * half_scale, X.y * half_scale});
         } else if constexpr (MODE == 5) {
           const float2 z = {X.x * half_scale, X.y * half_scale};
-          crow[k] = z;
+          store_bin<(C::N >= 2048)>(crow + k, z);
           if (mom_frame && k < p.mom_bins) {
             mom_s += (double)z.x + (double)z.y;
             mom_q += (double)z.x * (double)z.x + (double)z.y * (double)z.y;
@@ -735,9 +749,35 @@ __global__ __launch_bounds__(WG, C::OCC) void fwd_kernel(FwdParams p) {
 // ---------------------------------------------------------------------------
 //                    N     T   R0  R1  R2  PADQ
 using Cfg256 = FftCfg<256, 8, 16, 8, 1, 16>;
-using Cfg400 = FftCfg<400, 10, 20, 10, 1, 20>;
+// 400 and 800 points (n_fft / 2 = 2^3 5^2 and 2^4 5^2 complex points): twenty threads per frame
+// and ten points per thread and pass.  The two-pass plans these sizes had before (radix 20 x 10
+// and 20 x 20 over ten threads) kept 20 / 40 points and as many window taps, prefetched samples
+// and twiddles per thread: 256 registers plus 140 - 1 860 bytes of scratch per lane, and the
+// 800-point plan ran ten times below the power-of-two sizes' rate per n log n (256 x 30 s at
+// hop n_fft / 4, mel / stft: 5.53 / 4.59 ms -> 1.16 / 0.88 ms; 400 points 1.37 / 0.99 -> 1.00 /
+// 0.85 ms; tools/ab_sizes.sh).  800 points run under the register budget of one wave per SIMD
+// (the overflow goes to accumulation registers, not to memory).
+#ifndef MIA_CFG400
+#define MIA_CFG400 FftCfg<400, 20, 10, 2, 2, 10, 5>
+#endif
+#ifndef MIA_CFG800
+#define MIA_CFG800 FftCfg<800, 20, 10, 4, 10, 10, 1, 1>
+#endif
+#ifndef MIA_WG400
+#define MIA_WG400 256
+#endif
+#ifndef MIA_IT400
+#define MIA_IT400 4
+#endif
+#ifndef MIA_WG800
+#define MIA_WG800 128
+#endif
+#ifndef MIA_IT800
+#define MIA_IT800 4
+#endif
+using Cfg400 = MIA_CFG400;
 using Cfg512 = FftCfg<512, 32, 8, 8, 4, 8>;
-using Cfg800 = FftCfg<800, 10, 20, 20, 1, 20>;
+using Cfg800 = MIA_CFG800;
 // 1024, 2048 and 4096 points: eight points per thread and pass (four passes of radix 8 / 4, a
 // frame is one / two / four whole waves): half the per-thread state of a three-pass plan.
 // What that state buys is occupancy: with 256-thread workgroups, two frames per group and tile,
@@ -861,9 +901,9 @@ static int launch_cfg(const FwdParams& p0, hipStream_t s) {
 // group buffers plus the power tile stay under 80 KiB (two workgroups per CU).
 #define MIA_FWD_SIZES(X) \
   X(256, Cfg256, 256, 2)  \
-  X(400, Cfg400, 256, 2)  \
+  X(400, Cfg400, MIA_WG400, MIA_IT400)  \
   X(512, Cfg512, 256, 4)  \
-  X(800, Cfg800, 128, 2)  \
+  X(800, Cfg800, MIA_WG800, MIA_IT800)  \
   MIA_FWD_BIG(X)
 
 template <int MODE>

@@ -572,9 +572,19 @@ __global__ __launch_bounds__(C::T) void istft_own_kernel(InvParams p) {
 
 //                    N     T   R0  R1  R2  PADQ
 using Inv256 = InvCfg<256, 8, 8, 16, 1, 8>;
-using Inv400 = InvCfg<400, 10, 10, 20, 1, 10>;
+// 400 and 800 points: twenty threads per frame and ten / twenty points per thread in four passes
+// (the two-pass plans over ten threads needed 186 / 256 registers; inverse STFT of 256 x 30 s at
+// hop n_fft / 4: 1.72 -> 1.55 ms and 1.90 -> 1.58 ms, most of which is the frame workspace's
+// round trip through the overlap-add kernel; tools/ab_inv_sizes.sh).
+#ifndef MIA_INV400
+#define MIA_INV400 InvCfg<400, 20, 5, 2, 2, 5, 10>
+#endif
+#ifndef MIA_INV800
+#define MIA_INV800 InvCfg<800, 20, 10, 2, 2, 10, 10>
+#endif
+using Inv400 = MIA_INV400;
 using Inv512 = InvCfg<512, 32, 4, 8, 8, 4>;
-using Inv800 = InvCfg<800, 10, 20, 20, 1, 20>;
+using Inv800 = MIA_INV800;
 // 1024 / 2048 / 4096 points: eight points per thread and pass (four passes of radix 4 / 8), a
 // frame is one, two or four whole waves = the whole workgroup of the fused kernel
 // (istft_own_kernel), twiddles resident in registers.  Measured on the HTDemucs round trip
