@@ -12,7 +12,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-SOURCES = ["capi.hip", "ops.hip", "spectral_fwd.hip", "spectral_lane.hip", "spectral_inv.hip", "logmel400.hip", "resample.hip", "bigfft.hip", "features.hip", "onset.hip", "griffinlim.hip", "gate.hip", "normalize.hip", "stem.hip"]
+SOURCES = ["capi.hip", "ops.hip", "spectral_fwd.hip", "spectral_lane.hip", "spectral_wave.hip", "spectral_inv.hip", "logmel400.hip", "resample.hip", "bigfft.hip", "features.hip", "onset.hip", "griffinlim.hip", "gate.hip", "normalize.hip", "stem.hip"]
 HEADERS = ["fft_engine.h", "mia_internal.h", "w400_sweep_gen.inc", os.path.join(ROOT, "include", "mia.h")]
 LIB = os.path.join(HERE, "libmia_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function"]

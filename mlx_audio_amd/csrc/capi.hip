@@ -461,6 +461,10 @@ int mia_plan_create(const mia_plan_desc* d, mia_plan** out) {
   MIA_REQUIRE(d->pad_mode >= 0 && d->pad_mode <= 2, "bad pad_mode %d", d->pad_mode);
   mia_plan* p = new mia_plan();
   p->generic = fft_size_supported(d->n_fft) ? 0 : 1;  // no compiled kernel: the any-length engine
+  {
+    int np = 0, radix[6];
+    p->wave_fft = p->generic && forward_wave_plan(d->n_fft, &np, radix) ? 1 : 0;
+  }
   int rc = MIA_OK;
   auto fail = [&](int code) {
     plan_free(p);
@@ -567,6 +571,11 @@ int mia_plan_set_option(mia_plan* plan, const char* key, int value) {
     plan->opt_dpp_pass2 = value != 0;
     return MIA_OK;
   }
+  if (strcmp(key, "wave_fft") == 0) {  // 0: an any-length plan back on the whole-row engine (tests, A/B runs)
+    int np = 0, radix[6];
+    plan->wave_fft = value != 0 && plan->generic && forward_wave_plan(plan->n_fft, &np, radix) ? 1 : 0;
+    return MIA_OK;
+  }
   if (strcmp(key, "fwd_lane") == 0) {
     plan->opt_lane = value != 0;
     return MIA_OK;
@@ -647,13 +656,14 @@ int mia_stft(const mia_plan* plan, const float* y, int64_t B, int64_t T, float s
   int rc = fill_fwd(plan, y, B, T, p);
   if (rc != MIA_OK) return rc;
   MIA_REQUIRE(out != nullptr || B == 0, "null output");
-  if (plan->generic) {
+  if (plan->generic && !plan->wave_fft) {
     set_error("n_fft=%d has no compiled kernel: call mia_stft_ws with mia_stft_workspace_bytes() "
               "bytes of workspace", plan->n_fft);
     return MIA_ERR_INVALID;
   }
   p.scale = scale;
   p.cout = reinterpret_cast<float2*>(out);
+  if (plan->wave_fft) return launch_forward_wave(plan, p, 0, (hipStream_t)stream);
   return launch_forward(plan, p, 0, (hipStream_t)stream);
 }
 
@@ -686,7 +696,7 @@ int mia_stft_moments(const mia_plan* plan, const float* y, int64_t B, int64_t T,
 }
 
 size_t mia_stft_workspace_bytes(const mia_plan* plan, int64_t B, int64_t T) {
-  if (!plan || !plan->generic || B <= 0) return 0;
+  if (!plan || !plan->generic || plan->wave_fft || B <= 0) return 0;
   const int64_t F = mia_plan_num_frames(plan, T);
   return F <= 0 ? 0 : generic_fft_bytes(plan->n_fft, B * F);
 }
@@ -694,7 +704,7 @@ size_t mia_stft_workspace_bytes(const mia_plan* plan, int64_t B, int64_t T) {
 int mia_stft_ws(const mia_plan* plan, const float* y, int64_t B, int64_t T, float scale, void* out,
                 void* workspace, size_t workspace_bytes, void* stream) {
   MIA_REQUIRE(plan != nullptr, "null plan");
-  if (!plan->generic) return mia_stft(plan, y, B, T, scale, out, stream);
+  if (!plan->generic || plan->wave_fft) return mia_stft(plan, y, B, T, scale, out, stream);
   FwdParams p;
   int rc = fill_fwd(plan, y, B, T, p);
   if (rc != MIA_OK) return rc;
@@ -821,13 +831,14 @@ extern "C" size_t mia_mel_workspace_bytes(const mia_plan* plan, int64_t B, int64
   const int64_t F = mia_plan_num_frames(plan, T);
   if (F <= 0) return 0;
   const size_t keys = 2 * align256(sizeof(int) * (size_t)(B + 1));
-  return plan->generic ? keys + generic_fft_bytes(plan->n_fft, B * F) : keys;
+  return plan->generic && !plan->wave_fft ? keys + generic_fft_bytes(plan->n_fft, B * F) : keys;
 }
 
 // The n_fft = 400 kernel when the plan has its tables (and a clip's output fits the
 // kernel's 32-bit offsets), else the generic one.
 static int forward_mel_dispatch(const mia_plan* plan, const FwdParams& p, hipStream_t s,
                                 void* fft_ws = nullptr, size_t fft_ws_bytes = 0) {
+  if (plan->wave_fft) return launch_forward_wave(plan, p, 1, s);
   if (plan->generic) return launch_forward_generic(plan, p, 1, fft_ws, fft_ws_bytes, s);
   if (plan->d_sweep_meta != nullptr && p.n_mels * p.F < (1LL << 30)) {
     W400Tables tb{plan->d_win16, plan->d_tw16, plan->d_winp, plan->d_sweep_meta, plan->d_sweep_w,
@@ -839,6 +850,7 @@ static int forward_mel_dispatch(const mia_plan* plan, const FwdParams& p, hipStr
 }
 
 static bool mel_frame_major_ok(const mia_plan* plan) {
+  if (plan->wave_fft) return forward_wave_frame_major_ok(plan->n_fft, plan->n_mels);
   return !plan->generic && plan->d_sweep_meta == nullptr &&
          forward_frame_major_ok(plan->n_fft, plan->n_mels);
 }
@@ -891,7 +903,7 @@ static int mel_forward(const mia_plan* plan, const float* y, int64_t B, int64_t 
   { const char* e = getenv("MIA_DBG"); p.dbg = e ? atoi(e) : 0; }  // profiling builds only
 #endif
   const size_t keys_bytes = 2 * align256(sizeof(int) * (size_t)(B + 1));
-  if (plan->generic && B > 0) {
+  if (plan->generic && !plan->wave_fft && B > 0) {
     MIA_REQUIRE(workspace != nullptr && workspace_bytes >= mia_mel_workspace_bytes(plan, B, T),
                 "workspace too small (any-length plans need mia_mel_workspace_bytes() bytes)");
   }
@@ -933,7 +945,7 @@ int mia_melspectrogram_static(const mia_plan* plan, const float* y, int64_t B, i
                               int epilogue, float ref, float amin, float coef, float top_db,
                               int per_clip, float* out, void* stream) {
   MIA_REQUIRE(plan != nullptr, "null plan");
-  MIA_REQUIRE(!plan->generic, "n_fft=%d has no compiled kernel: its any-length plan needs the "
+  MIA_REQUIRE(!plan->generic || plan->wave_fft, "n_fft=%d has no compiled kernel: its any-length plan needs the "
               "workspace of mia_melspectrogram", plan->n_fft);
   MIA_REQUIRE(B <= MIA_STATIC_MAX_CLIPS,
               "mia_melspectrogram_static holds clamp keys for at most %d clips, got %lld "

@@ -101,6 +101,8 @@ struct mia_plan {
   int cus = 256;                 // compute units of the device (sizes the persistent grids)
   // any-length plan (n_fft without a compiled LDS kernel): whole-row engine of bigfft.hip
   int generic = 0;
+  int wave_fft = 0;              // ... whose forward transform (spectrum and mel modes) the per-wave kernel of
+                                 // spectral_wave.hip serves without a workspace (even n_fft <= 2048, 7-smooth)
   float2* d_chirp = nullptr;     // chirp-z path only: exp(i pi n^2 / n_fft)
   float2* d_bspec = nullptr;     // ... and the spectrum of the convolution kernel
   int opt_table_sweep = 0;       // mia_plan_set_option("w400_table_sweep"): ablation / test knob
@@ -224,6 +226,9 @@ int forward_tile_frames(int n_fft, int mode);
 bool forward_frame_major_ok(int n_fft, int n_mels);
 bool forward_lane_ok(int n_fft, int hop, int n_mels, int nnz);
 int launch_forward_lane(const FwdParams& p, int cus, hipStream_t s);
+bool forward_wave_plan(int n_fft, int* n_pass, int radix[6]);
+bool forward_wave_frame_major_ok(int n_fft, int n_mels);
+int launch_forward_wave(const mia_plan* plan, const FwdParams& p, int mode, hipStream_t s);
 bool dct2_frame_major_ok(int n_in, int n_out);
 int launch_dct2_frame_major(const float* x, long long outer, int n_in, long long inner, const float* basis,
                             int n_out, float* out, const int* keys, long long key_stride, float top,

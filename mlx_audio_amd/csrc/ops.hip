@@ -330,7 +330,8 @@ __global__ __launch_bounds__(256) void dct2_kernel(const float* __restrict__ x, 
 //   B(ks)    : lane l holds x[4 ks + l / 16][16 w + l % 16]         (from the LDS slab)
 //   D(mb)    : lane l holds rows 16 mb + 4 (l / 16) + r, r = 0..3, of position 16 w + l % 16
 typedef float dct_floatx4 __attribute__((ext_vector_type(4)));
-constexpr int kDctMB = 3, kDctKS = 32;  // 48 rows, 128 taps
+constexpr int kDctMaxMB = 3, kDctKS = 32;  // up to 48 rows (MB blocks of 16), 128 taps
+template <int kDctMB>
 __global__ __launch_bounds__(256) void dct2_mfma_kernel(const float* __restrict__ x, int n_in,
                                                          long long inner,
                                                          const float* __restrict__ basis, int n_out,
@@ -352,8 +353,12 @@ __global__ __launch_bounds__(256) void dct2_mfma_kernel(const float* __restrict_
       a[mb][ks] = (m < n_out && k < n_in) ? basis[(long long)m * n_in + k] : 0.0f;
     }
   }
-  const long long first = (long long)blockIdx.x * tiles_per_wg;
-  const long long last = first + tiles_per_wg < total ? first + tiles_per_wg : total;
+  // Tiles are dealt round-robin: at any moment the resident workgroups read neighbouring
+  // 256-byte pieces of the same rows (rows are `inner` floats apart, pieces of one tile lie in
+  // n_in different rows), so that a row's lines and DRAM pages are used up together instead of
+  // every workgroup streaming through its own n_in rows.
+  const long long first = blockIdx.x, last = total, step = gridDim.x;
+  (void)tiles_per_wg;
   // The tile's inputs are fetched one tile ahead into registers (they fly during the
   // MFMAs of the current tile) and reach the slab, floored, after its last reader.
   float nx[32];
@@ -370,7 +375,7 @@ __global__ __launch_bounds__(256) void dct2_mfma_kernel(const float* __restrict_
     }
   };
   fetch(first);
-  for (long long idx = first; idx < last; ++idx) {
+  for (long long idx = first; idx < last; idx += step) {
     const long long o = idx / tiles_per_row;
     const long long i0 = (idx - o * tiles_per_row) * 64;
     const float thr = keys ? floor_from_key(nkey, MIA_EPI_DB, top) : -INFINITY;
@@ -380,7 +385,7 @@ __global__ __launch_bounds__(256) void dct2_mfma_kernel(const float* __restrict_
       slab[n * 64 + lane] = n < n_in ? floor_nan(nx[j], thr) : 0.0f;
     }
     __syncthreads();
-    fetch(idx + 1);
+    fetch(idx + step);
     float bv[kDctKS];
 #pragma unroll
     for (int ks = 0; ks < kDctKS; ++ks) bv[ks] = slab[(4 * ks + kq) * 64 + 16 * wave + row];
@@ -417,6 +422,7 @@ __global__ __launch_bounds__(256) void dct2_mfma_kernel(const float* __restrict_
 // writes for the MFCC path: a tile of 64 positions is one contiguous run of 64 * n_in floats).
 // Needs n_in % 4 == 0.  The slab is [position][n_in + 4]: whole float4 stores when staging, and
 // the B operand reads (16 positions x 4 taps per wave instruction) are 2-way at most.
+template <int kDctMB>
 __global__ __launch_bounds__(256) void dct2_mfma_fm_kernel(const float* __restrict__ x, int n_in,
                                                             long long inner,
                                                             const float* __restrict__ basis, int n_out,
@@ -506,8 +512,24 @@ __global__ __launch_bounds__(256) void dct2_mfma_fm_kernel(const float* __restri
   }
 }
 
+// Workgroups of a matrix-core DCT kernel that one CU holds (by its registers and its LDS slab),
+// asked once per instantiation and device.
+static int dct_resident_per_cu(const void* kern, int which) {
+  static int cached[2 * kDctMaxMB][16] = {{0}};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+  if (cached[which][dev] == 0) {
+    int per_cu = 2;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, 0) != hipSuccess || per_cu < 1) {
+      per_cu = 2;
+    }
+    cached[which][dev] = per_cu;
+  }
+  return cached[which][dev];
+}
+
 bool dct2_frame_major_ok(int n_in, int n_out) {
-  return n_in <= 4 * kDctKS && n_out <= 16 * kDctMB && n_in >= 32 && n_in % 4 == 0;
+  return n_in <= 4 * kDctKS && n_out <= 16 * kDctMaxMB && n_in >= 32 && n_in % 4 == 0;
 }
 
 int launch_dct2_frame_major(const float* x, long long outer, int n_in, long long inner, const float* basis,
@@ -524,7 +546,11 @@ int launch_dct2_frame_major(const float* x, long long outer, int n_in, long long
   if (hipGetDevice(&dev) == hipSuccess) {
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   }
-  long long grid = 2LL * cus;
+  // one instantiation per number of 16-row blocks of the basis: fewer blocks, fewer resident
+  // operand registers and matrix instructions (13 or 20 coefficients instead of 40)
+  const int mb = n_out <= 16 ? 1 : (n_out <= 32 ? 2 : 3);
+  auto kern = mb == 1 ? dct2_mfma_fm_kernel<1> : (mb == 2 ? dct2_mfma_fm_kernel<2> : dct2_mfma_fm_kernel<3>);
+  long long grid = (long long)cus * dct_resident_per_cu(reinterpret_cast<const void*>(kern), mb - 1);
   if (grid > total) grid = total;
   const long long per_wg = (total + grid - 1) / grid;
   if (per_wg > 0x7fffffffLL) {
@@ -532,7 +558,7 @@ int launch_dct2_frame_major(const float* x, long long outer, int n_in, long long
     return MIA_ERR_UNSUPPORTED;
   }
   grid = (total + per_wg - 1) / per_wg;
-  hipLaunchKernelGGL(dct2_mfma_fm_kernel, dim3((unsigned)grid), dim3(256), 0, s, x, n_in, inner, basis,
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), 0, s, x, n_in, inner, basis,
                      n_out, out, keys, key_stride, top, tiles_per_row, total, (int)per_wg);
   MIA_CHECK_HIP(hipGetLastError());
   return MIA_OK;
@@ -542,19 +568,21 @@ int launch_dct2(const float* x, long long outer, int n_in, long long inner, cons
                 int n_out, float* out, const int* keys, long long key_stride, float top,
                 hipStream_t s) {
   if (outer <= 0 || inner <= 0 || n_out <= 0) return MIA_OK;
-  if (n_in <= 4 * kDctKS && n_out <= 16 * kDctMB && n_in >= 32) {
+  if (n_in <= 4 * kDctKS && n_out <= 16 * kDctMaxMB && n_in >= 32) {
     const long long tiles_per_row = (inner + 63) / 64;
     const long long total = outer * tiles_per_row;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) {
       (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     }
-    long long grid = 2LL * cus;  // 32 KB of LDS, < 256 VGPRs: two workgroups per CU
+    const int mb = n_out <= 16 ? 1 : (n_out <= 32 ? 2 : 3);
+    auto kern = mb == 1 ? dct2_mfma_kernel<1> : (mb == 2 ? dct2_mfma_kernel<2> : dct2_mfma_kernel<3>);
+    long long grid = (long long)cus * dct_resident_per_cu(reinterpret_cast<const void*>(kern), kDctMaxMB + mb - 1);
     if (grid > total) grid = total;
     const long long per_wg = (total + grid - 1) / grid;
     if (per_wg <= 0x7fffffffLL) {
       grid = (total + per_wg - 1) / per_wg;
-      hipLaunchKernelGGL(dct2_mfma_kernel, dim3((unsigned)grid), dim3(256), 0, s, x, n_in, inner,
+      hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), 0, s, x, n_in, inner,
                          basis, n_out, out, keys, key_stride, top, tiles_per_row, total, (int)per_wg);
       MIA_CHECK_HIP(hipGetLastError());
       return MIA_OK;

@@ -748,7 +748,13 @@ __global__ __launch_bounds__(WG, C::OCC) void fwd_kernel(FwdParams p) {
 // Size table and dispatch
 // ---------------------------------------------------------------------------
 //                    N     T   R0  R1  R2  PADQ
-using Cfg256 = FftCfg<256, 8, 16, 8, 1, 16>;
+#ifndef MIA_CFG256
+#define MIA_CFG256 FftCfg<256, 8, 16, 8, 1, 16>
+#endif
+#ifndef MIA_IT256
+#define MIA_IT256 2
+#endif
+using Cfg256 = MIA_CFG256;
 // 400 and 800 points (n_fft / 2 = 2^3 5^2 and 2^4 5^2 complex points): twenty threads per frame
 // and ten points per thread and pass.  The two-pass plans these sizes had before (radix 20 x 10
 // and 20 x 20 over ten threads) kept 20 / 40 points and as many window taps, prefetched samples
@@ -900,7 +906,7 @@ static int launch_cfg(const FwdParams& p0, hipStream_t s) {
 // Per size: workgroup threads and frames per group (ITERS), chosen so that the
 // group buffers plus the power tile stay under 80 KiB (two workgroups per CU).
 #define MIA_FWD_SIZES(X) \
-  X(256, Cfg256, 256, 2)  \
+  X(256, Cfg256, 256, MIA_IT256)  \
   X(400, Cfg400, MIA_WG400, MIA_IT400)  \
   X(512, Cfg512, 256, 4)  \
   X(800, Cfg800, MIA_WG800, MIA_IT800)  \

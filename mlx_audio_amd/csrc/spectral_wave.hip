@@ -1,0 +1,371 @@
+// Forward transform for the n_fft that have no compiled plan: any even n_fft up to 2048 whose
+// half length factors into butterflies of at most 16 points (2^a 3^b 5^c 7^d: 320, 480, 640,
+// 882, 960, 1200, 1536, 1764, ...).  The reference takes any n_fft at one speed (mx.fft.rfft,
+// primitives/stft.py:109-133); the whole-row engine of bigfft.hip, which served these sizes
+// alone before, gathers the frames into a workspace and makes several trips through memory
+// (64 x 30 s at n_fft 960: 3.9 ms against 0.15 ms for the compiled 1024-point plan).
+//
+// Here a frame belongs to ONE wave: its n_fft / 2 complex points sit in the wave's own two LDS
+// buffers and go through Stockham passes whose radices are run-time data (a switch over the
+// butterfly templates; lanes take butterflies lane, lane + 64, ...), twiddles from a table of
+// exp(-2 pi i k / (n_fft / 2)) in LDS.  No workgroup barrier stands in the frame loop - LDS
+// operations of one wave complete in order.  Split step, spectrum rows / power tile, band
+// projection and epilogues are those of the compiled plans (spectral_fwd.hip); a workgroup is
+// four waves and a tile eight frames.  Per n log n it runs at a third to a half of the compiled
+// plans' rate, which is what run-time radices and 4 - 12 waves per CU cost.
+#include "fft_engine.h"
+#include "mia_internal.h"
+
+namespace mia {
+namespace wavefft {
+
+constexpr int WG = 256, WAVES = WG / 64, FPW = 2, FT = WAVES * FPW;
+constexpr int MAXP = 6, MAXM = 1024;
+
+struct Passes {
+  int n;
+  int radix[MAXP];
+};
+
+// LDS slot of logical element i: one pad slot per 16 elements, so that the strided writes of a
+// pass (lane j writes j R + r, ...) spread over the banks.
+__host__ __device__ __forceinline__ int pos(int i) { return i + (i >> 4); }
+__host__ __device__ inline int buf_len(int M) { return M + (M >> 4) + 2; }
+
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// One Stockham pass of radix R after passes whose radices multiply to NS (inv_ns = 1 / NS).
+template <int R>
+__device__ __forceinline__ void pass(const float2* __restrict__ src, float2* __restrict__ dst,
+                                     const float2* __restrict__ twM, int M, int NS, float inv_ns,
+                                     int lane) {
+  const int S = M / R;
+  const int tstep = S / NS;  // step in the table of exp(-2 pi i k / M)
+  for (int j = lane; j < S; j += 64) {
+    // j / NS and j mod NS without an integer division: exact for j < 2^20
+    const int q = NS == 1 ? j : (int)(((float)j + 0.5f) * inv_ns);
+    const int jm = j - q * NS;
+    float2 v[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      float2 x = src[pos(j + r * S)];
+      if (r > 0 && NS > 1) x = cmul(x, twM[jm * r * tstep]);
+      v[r] = x;
+    }
+    Dft<R>::run(v);
+    const int base = q * NS * R + jm;
+#pragma unroll
+    for (int r = 0; r < R; ++r) dst[pos(base + r * NS)] = v[r];
+  }
+}
+
+template <int MODE>  // 0: spectrum rows, 1: mel (B, n_mels, F), 3: mel (B, F, n_mels)
+__global__ __launch_bounds__(WG) void fwd_wave_kernel(FwdParams p, Passes ps, int M) {
+  constexpr bool MEL = MODE != 0;
+  const int N = 2 * M;
+  const int LB = buf_len(M);
+  const int PS = (M + 1) | 1;  // odd row stride of the power tile
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float2* const bufs = reinterpret_cast<float2*>(smem_raw);      // [WAVES][2][LB]
+  float2* const twM = bufs + WAVES * 2 * LB;                      // [M]
+  float* const P = reinterpret_cast<float*>(twM + M);             // [FT][PS] (mel modes)
+  float* const lds_wts = P + (MEL ? FT * PS : 0);
+  int* const lds_rows = reinterpret_cast<int*>(lds_wts + (MEL ? p.nnz : 0));
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int k = tid; k < M; k += WG) twM[k] = p.tw[2 * k];
+  if constexpr (MEL) {
+    if (p.lds_tables) {
+      for (int i = tid; i < p.nnz; i += WG) lds_wts[i] = p.wts[i];
+      for (int i = tid; i < p.n_mels; i += WG) {
+        lds_rows[i] = p.row_lo[i];
+        lds_rows[p.n_mels + i] = p.row_len[i];
+        lds_rows[2 * p.n_mels + i] = p.row_off[i];
+      }
+    }
+  }
+  __syncthreads();
+
+  float2* const bufA = bufs + wave * 2 * LB;
+  float2* const bufB = bufA + LB;
+  const float2* __restrict__ win2 = reinterpret_cast<const float2*>(p.win);
+  const float half_scale = 0.5f * p.scale;
+
+  const long long total = p.B * p.tiles;
+  const long long first = (long long)blockIdx.x * p.tiles_per_wg;
+  const long long last = first + p.tiles_per_wg < total ? first + p.tiles_per_wg : total;
+  for (long long idx = first; idx < last; ++idx) {
+    const long long b = (long long)((unsigned)idx / (unsigned)p.tiles);  // the launcher keeps the tile count below 2^32
+    const int tile = (int)(idx - b * p.tiles);
+    const long long f0 = (long long)tile * FT;
+    const float* __restrict__ yb = p.y + b * p.T;
+
+    for (int i = 0; i < FPW; ++i) {
+      const int fl = wave * FPW + i;
+      const long long f = f0 + fl;
+      if (f >= p.F) break;  // wave-uniform
+      // ---- windowed sample pairs z[n] = x[2 n] + i x[2 n + 1] --------------------------------
+      const long long s0 = f * p.hop - p.pad;
+      const bool interior = s0 >= 0 && s0 + N <= p.T;
+      if (interior && (reinterpret_cast<uintptr_t>(yb + s0) & 7) == 0) {
+        const float2* __restrict__ src = reinterpret_cast<const float2*>(yb + s0);
+        for (int n = lane; n < M; n += 64) {
+          const float2 x = src[n], w = win2[n];
+          bufA[pos(n)] = {x.x * w.x, x.y * w.y};
+        }
+      } else if (interior) {
+        for (int n = lane; n < M; n += 64) {
+          const float2 w = win2[n];
+          bufA[pos(n)] = {yb[s0 + 2 * n] * w.x, yb[s0 + 2 * n + 1] * w.y};
+        }
+      } else {
+        for (int n = lane; n < M; n += 64) {
+          const float2 w = win2[n];
+          bufA[pos(n)] = {fetch_sample(yb, p.T, s0 + 2 * n, p.pad_mode) * w.x,
+                          fetch_sample(yb, p.T, s0 + 2 * n + 1, p.pad_mode) * w.y};
+        }
+      }
+      wave_sync();
+      // ---- Stockham passes, ping-pong between the wave's two buffers --------------------------
+      const float2* src = bufA;
+      float2* dst = bufB;
+      int NS = 1;
+      for (int pi = 0; pi < ps.n; ++pi) {
+        const int R = ps.radix[pi];
+        const float inv_ns = 1.0f / (float)NS;
+        switch (R) {
+          case 2: pass<2>(src, dst, twM, M, NS, inv_ns, lane); break;
+          case 3: pass<3>(src, dst, twM, M, NS, inv_ns, lane); break;
+          case 4: pass<4>(src, dst, twM, M, NS, inv_ns, lane); break;
+          case 5: pass<5>(src, dst, twM, M, NS, inv_ns, lane); break;
+          case 6: pass<6>(src, dst, twM, M, NS, inv_ns, lane); break;
+          case 7: pass<7>(src, dst, twM, M, NS, inv_ns, lane); break;
+          case 8: pass<8>(src, dst, twM, M, NS, inv_ns, lane); break;
+          case 10: pass<10>(src, dst, twM, M, NS, inv_ns, lane); break;
+          case 12: pass<12>(src, dst, twM, M, NS, inv_ns, lane); break;
+          case 15: pass<15>(src, dst, twM, M, NS, inv_ns, lane); break;
+          default: pass<16>(src, dst, twM, M, NS, inv_ns, lane); break;
+        }
+        wave_sync();
+        float2* const t = const_cast<float2*>(src);
+        src = dst;
+        dst = t;
+        NS *= R;
+      }
+      // ---- split step: bins k and M - k from Z[k] and Z[M - k] --------------------------------
+      // E = U + conj(V);  O = -i (U - conj(V));  X[k] = (E + w O) / 2,  X[M - k] = conj(E - w O) / 2
+      float2* __restrict__ crow = MODE == 0 ? p.cout + (b * p.F + f) * (long long)(M + 1) : nullptr;
+      float* __restrict__ prow = P + fl * PS;
+      for (int k = lane; 2 * k <= M; k += 64) {
+        const float2 U = src[pos(k)];
+        const float2 V = src[pos(k == 0 ? 0 : M - k)];
+        const float2 w = p.tw[k];
+        const float2 E = {U.x + V.x, U.y - V.y};
+        const float2 O = {U.y + V.y, V.x - U.x};
+        const float2 WO = cmul(O, w);
+        const float2 X1 = {E.x + WO.x, E.y + WO.y};
+        const float2 X2 = {E.x - WO.x, WO.y - E.y};
+        if constexpr (MODE == 0) {
+          crow[k] = {X1.x * half_scale, X1.y * half_scale};
+          if (2 * k != M) crow[M - k] = {X2.x * half_scale, X2.y * half_scale};
+        } else {
+          prow[k] = 0.25f * (X1.x * X1.x + X1.y * X1.y);
+          if (2 * k != M) prow[M - k] = 0.25f * (X2.x * X2.x + X2.y * X2.y);
+        }
+      }
+      wave_sync();  // the next frame overwrites the buffers
+    }
+
+    if constexpr (MEL) {
+      __syncthreads();
+      const long long frem = p.F - f0;
+      const int fcount = frem < FT ? (int)frem : FT;
+      if (p.power_mode != 0) {  // magnitudes or |X|^p instead of powers
+        for (int i = tid; i < fcount * PS; i += WG) {
+          const int k = i % PS;
+          if (k <= M) {
+            const float mag = sqrtf(P[i]);
+            P[i] = p.power_mode == 1 ? mag : powf(mag, p.power);
+          }
+        }
+        __syncthreads();
+      }
+      int kmax = kKeyMinusInf;  // integer keys: a NaN value wins the maximum, as in the reference
+      float vmin = INFINITY;
+      float* const stage = reinterpret_cast<float*>(bufs);  // frame-major rows leave through the idle FFT buffers
+      auto project = [&](const int* row_lo, const int* row_len, const int* row_off, const float* wts) {
+        for (int idx2 = tid; idx2 < p.n_mels * FT; idx2 += WG) {
+          const int m = idx2 / FT;
+          const int fl = idx2 - m * FT;
+          if (fl >= fcount) continue;
+          const int lo = row_lo[m], len = row_len[m];
+          const float* w = wts + row_off[m];
+          const float* __restrict__ pr = P + fl * PS + lo;
+          float acc = 0.0f;
+#pragma unroll 4
+          for (int j = 0; j < len; ++j) acc = fmaf(w[j], pr[j], acc);
+          float outv = acc;
+          if (p.epi == MIA_EPI_WHISPER) {
+            // values at or below the 1e-10 floor give exactly log10(1e-10) = -10
+            const float yv = acc <= 1e-10f ? -10.0f : __log10f(acc);
+            kmax = max(kmax, float_to_key_nan(yv));
+            outv = (yv + 4.0f) * 0.25f;
+            vmin = fminf(vmin, outv);
+          } else if (p.epi == MIA_EPI_DB) {
+            outv = acc <= p.amin ? p.db_floor : p.coef * __log10f(acc * p.inv_ref);
+            kmax = max(kmax, float_to_key_nan(outv));
+            vmin = fminf(vmin, outv);
+          }
+          if (MODE == 3) {
+            stage[fl * p.n_mels + m] = outv;
+          } else {
+            p.mout[(b * p.n_mels + m) * p.F + f0 + fl] = outv;
+          }
+        }
+      };
+      if (p.lds_tables) {
+        project(lds_rows, lds_rows + p.n_mels, lds_rows + 2 * p.n_mels, lds_wts);
+      } else {
+        project(p.row_lo, p.row_len, p.row_off, p.wts);
+      }
+      if (MODE == 3) {
+        __syncthreads();
+        float* __restrict__ dstp = p.mout + (b * p.F + f0) * p.n_mels;  // 16-byte aligned: n_mels % 4 == 0
+        const int n4 = fcount * p.n_mels / 4;
+        for (int i = tid; i < n4; i += WG) {
+          reinterpret_cast<float4*>(dstp)[i] = reinterpret_cast<const float4*>(stage)[i];
+        }
+      }
+      if (p.epi != MIA_EPI_NONE && p.clip_max_key != nullptr) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+          kmax = max(kmax, __shfl_xor(kmax, off));
+          vmin = fminf(vmin, __shfl_xor(vmin, off));
+        }
+        __shared__ int red_max[WAVES];
+        __shared__ float red_min[WAVES];
+        if (lane == 0) {
+          red_max[wave] = kmax;
+          red_min[wave] = vmin;
+        }
+        __syncthreads();
+        if (tid == 0) {
+#pragma unroll
+          for (int w = 1; w < WAVES; ++w) {
+            kmax = max(kmax, red_max[w]);
+            vmin = fminf(vmin, red_min[w]);
+          }
+          atomicMax(p.clip_max_key + b, kmax);
+          atomicMin(p.clip_min_key + b, float_to_key(vmin));
+        }
+      }
+      __syncthreads();  // the next tile overwrites the power tile, the buffers and the reduction slots
+    }
+  }
+}
+
+static size_t lds_bytes(int M, int mode, int n_mels, int nnz, bool with_tables) {
+  size_t b = sizeof(float2) * ((size_t)WAVES * 2 * buf_len(M) + M);
+  if (mode != 0) {
+    b += sizeof(float) * (size_t)FT * ((M + 1) | 1);
+    if (with_tables) b += sizeof(float) * (size_t)nnz + 3 * sizeof(int) * (size_t)n_mels;
+  }
+  return b;
+}
+
+}  // namespace wavefft
+
+// The butterflies of the plan for n_fft (largest first), or false: odd n_fft, a half length above
+// 1024, a prime factor above 7 or more than six passes.
+bool forward_wave_plan(int n_fft, int* n_pass, int radix[6]) {
+  using namespace wavefft;
+  if (n_fft < 4 || n_fft % 2 != 0 || n_fft / 2 > MAXM) return false;
+  static const int allowed[] = {16, 15, 12, 10, 8, 7, 6, 5, 4, 3, 2};
+  int rem = n_fft / 2, n = 0;
+  while (rem > 1) {
+    int pick = 0;
+    for (int r : allowed) {
+      if (rem % r == 0) {
+        pick = r;
+        break;
+      }
+    }
+    if (pick == 0 || n == MAXP) return false;
+    radix[n++] = pick;
+    rem /= pick;
+  }
+  *n_pass = n;
+  return n >= 1;
+}
+
+// Mel modes keep eight power rows beside the buffers: they fit for every size the plan covers;
+// frame-major rows additionally leave through the FFT buffers.
+bool forward_wave_frame_major_ok(int n_fft, int n_mels) {
+  using namespace wavefft;
+  return n_mels % 4 == 0 &&
+         sizeof(float) * (size_t)FT * n_mels <= sizeof(float2) * (size_t)WAVES * 2 * buf_len(n_fft / 2);
+}
+
+int forward_wave_tile_frames() { return wavefft::FT; }
+
+int launch_forward_wave(const mia_plan* plan, const FwdParams& p0, int mode, hipStream_t s) {
+  using namespace wavefft;
+  Passes ps{};
+  if (!forward_wave_plan(plan->n_fft, &ps.n, ps.radix)) {
+    set_error("n_fft=%d is not served by the per-wave transform", plan->n_fft);
+    return MIA_ERR_UNSUPPORTED;
+  }
+  const int M = plan->n_fft / 2;
+  FwdParams p = p0;
+  const int kmode = mode == 0 ? 0 : (p.frame_major ? 3 : 1);
+  if (kmode == 3 && !forward_wave_frame_major_ok(plan->n_fft, p.n_mels)) {
+    set_error("frame-major mel rows do not fit this plan's FFT buffers");
+    return MIA_ERR_UNSUPPORTED;
+  }
+  p.tiles = (int)((p.F + FT - 1) / FT);
+  const long long total = p.B * p.tiles;
+  if (total <= 0) return MIA_OK;
+  if (total >= 0xffffffffLL) {  // the kernel divides tile indices in 32 bits
+    set_error("%lld tiles do not fit one launch (split the batch)", total);
+    return MIA_ERR_UNSUPPORTED;
+  }
+  size_t lds = lds_bytes(M, kmode, p.n_mels, p.nnz, false);
+  p.lds_tables = 0;
+  if (kmode != 0 && lds_bytes(M, kmode, p.n_mels, p.nnz, true) <= 80 * 1024) {
+    lds = lds_bytes(M, kmode, p.n_mels, p.nnz, true);  // band tables ride along while two workgroups fit a CU
+    p.lds_tables = 1;
+  }
+  if (lds > 160 * 1024) {
+    set_error("n_fft=%d: %zu bytes of LDS", plan->n_fft, lds);
+    return MIA_ERR_UNSUPPORTED;
+  }
+  auto kern = kmode == 0 ? fwd_wave_kernel<0> : (kmode == 1 ? fwd_wave_kernel<1> : fwd_wave_kernel<3>);
+  if (lds > 64 * 1024) {
+    MIA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  }
+  int per_cu = 1;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), WG, lds) !=
+          hipSuccess || per_cu < 1) {
+    per_cu = 1;
+  }
+  long long grid = (long long)(plan->cus > 0 ? plan->cus : 256) * per_cu;
+  if (grid > total) grid = total;
+  const long long per_wg = (total + grid - 1) / grid;
+  if (per_wg > 0x7fffffffLL) {
+    set_error("batch too large for one launch: %lld tiles (split the batch)", total);
+    return MIA_ERR_UNSUPPORTED;
+  }
+  p.tiles_per_wg = (int)per_wg;
+  grid = (total + per_wg - 1) / per_wg;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WG), lds, s, p, ps, M);
+  MIA_CHECK_HIP(hipGetLastError());
+  return MIA_OK;
+}
+
+}  // namespace mia

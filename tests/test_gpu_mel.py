@@ -365,3 +365,41 @@ def test_wave_private_kernel_option(gpu, hop, n_mels, pad_mode, served):
                                    pad_mode=pad_mode).transpose(0, 2, 1)
             np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=1e-4, atol=1e-5 * ref.max())
             np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=2e-5, atol=1e-6 * ref.max())
+
+
+@pytest.mark.parametrize("n_fft,hop,n_mels,sr", [(480, 160, 80, 16000), (960, 480, 64, 48000), (882, 441, 40, 44100),
+                                                (1200, 300, 128, 48000), (320, 80, 24, 16000)])
+def test_mel_chain_on_the_per_wave_transform(gpu, n_fft, hop, n_mels, sr):
+    """n_fft without a compiled plan but with a 7-smooth half length (20 / 30 ms windows at 16,
+    44.1 and 48 kHz): mel power, magnitude mel, dB with a per-clip top_db floor, frame-major rows and
+    MFCC against the oracle; rows of a batch equal the rows computed alone."""
+    from mlx_audio_amd import _lib
+    from mlx_audio_amd.primitives import melspectrogram, mfcc, power_to_db
+    from mlx_audio_amd.primitives.mel import _mel_raw
+
+    assert _lib.lib().mia_fft_size_supported(n_fft) == 0
+    g = torch.Generator(device="cuda").manual_seed(n_fft + n_mels)
+    y = 0.3 * torch.randn((3, 9 * n_fft + 123), device=gpu, generator=g)
+    y[1, : 4 * n_fft] *= 1e-4
+    x = y.cpu().numpy()
+    got = melspectrogram(y, sr=sr, n_fft=n_fft, hop_length=hop, n_mels=n_mels, pad_mode="reflect")
+    ref = o.melspectrogram(x, sr=sr, n_fft=n_fft, hop_length=hop, n_mels=n_mels, pad_mode="reflect")
+    np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=1e-4, atol=1e-5 * ref.max())
+    one = melspectrogram(y[1], sr=sr, n_fft=n_fft, hop_length=hop, n_mels=n_mels, pad_mode="reflect")
+    assert torch.equal(one, got[1])
+    got1 = melspectrogram(y, sr=sr, n_fft=n_fft, hop_length=hop, n_mels=n_mels, power=1.0)
+    ref1 = o.melspectrogram(x, sr=sr, n_fft=n_fft, hop_length=hop, n_mels=n_mels, power=1.0)
+    np.testing.assert_allclose(got1.cpu().numpy(), ref1, rtol=1e-4, atol=1e-5 * ref1.max())
+    # dB with the floor 60 dB below each clip's maximum, row-major and frame-major
+    args = (y, sr, n_fft, hop, None, "hann", True, "constant", 2.0, n_mels, 0.0, None, False, "slaney")
+    kw = {"epilogue": _lib.EPI_DB, "top_db": 60.0, "per_clip": True}
+    a = _mel_raw(*args, **kw)
+    want = np.stack([o.power_to_db(o.melspectrogram(x[i], sr=sr, n_fft=n_fft, hop_length=hop, n_mels=n_mels),
+                                   top_db=60.0) for i in range(3)])
+    assert np.abs(a.cpu().numpy() - want).max() <= 2e-3
+    b = _mel_raw(*args, frames_first=True, **kw)
+    assert b.shape == (3, a.shape[2], n_mels) and torch.equal(a.transpose(1, 2), b)
+    assert b.is_contiguous() == (n_mels % 4 == 0)
+    c = mfcc(y, sr=sr, n_mfcc=13, n_fft=n_fft, hop_length=hop, n_mels=n_mels, per_clip=True)
+    wantc = np.stack([o.mfcc(x[i], sr=sr, n_mfcc=13, n_fft=n_fft, hop_length=hop, n_mels=n_mels) for i in range(3)])
+    np.testing.assert_allclose(c.cpu().numpy(), wantc, rtol=1e-4, atol=5e-3)

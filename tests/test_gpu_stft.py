@@ -331,13 +331,69 @@ def test_any_length_plans_reject_the_entry_points_without_workspace(gpu):
     from mlx_audio_amd.primitives.windows import padded_window_np
 
     lib = _lib.lib()
-    assert lib.mia_fft_size_supported(300) == 0 and lib.mia_fft_size_supported(400) == 1
+    assert lib.mia_fft_size_supported(441) == 0 and lib.mia_fft_size_supported(400) == 1
+    # an odd n_fft runs on the whole-row engine, which needs its workspace
+    plan = get_plan(gpu, 441, 110, True, "constant", padded_window_np("hann", 441, 441))
+    y = torch.zeros((1, 2000), device=gpu)
+    out = torch.empty((1, plan.num_frames(2000), 221), dtype=torch.complex64, device=gpu)
+    assert lib.mia_stft_workspace_bytes(plan.handle, 1, 2000) > 0
+    rc = lib.mia_stft(plan.handle, y.data_ptr(), 1, 2000, 1.0, out.data_ptr(), None)
+    assert rc == _lib.MIA_ERR_INVALID and b"mia_stft_ws" in lib.mia_last_error()
+    # an even 7-smooth n_fft up to 2048 has no compiled plan either but is served by the per-wave
+    # kernel: no workspace, the plain entry point works
     plan = get_plan(gpu, 300, 75, True, "constant", padded_window_np("hann", 300, 300))
+    assert lib.mia_fft_size_supported(300) == 0
+    assert lib.mia_stft_workspace_bytes(plan.handle, 1, 1000) == 0
     y = torch.zeros((1, 1000), device=gpu)
     out = torch.empty((1, plan.num_frames(1000), 151), dtype=torch.complex64, device=gpu)
-    assert lib.mia_stft_workspace_bytes(plan.handle, 1, 1000) > 0
-    rc = lib.mia_stft(plan.handle, y.data_ptr(), 1, 1000, 1.0, out.data_ptr(), None)
-    assert rc == _lib.MIA_ERR_INVALID and b"mia_stft_ws" in lib.mia_last_error()
+    _lib.check(lib.mia_stft(plan.handle, y.data_ptr(), 1, 1000, 1.0, out.data_ptr(), None))
+    torch.cuda.synchronize()
+    assert float(out.abs().max()) == 0.0
+
+
+WAVE_SIZES = [4, 6, 24, 98, 300, 320, 480, 640, 882, 960, 1200, 1536, 1764, 2000, 2016, 2048 - 2 * 7]
+
+
+@pytest.mark.parametrize("n_fft", WAVE_SIZES)
+def test_per_wave_transform_sizes(gpu, n_fft):
+    """Even n_fft up to 2048 with a 7-smooth half length (radices 2 ... 16 in every mix: 882 =
+    2 (7 7 3 3), 960 = 2 (16 15 2), 2000 = 2 (10 10 10), ...): spectrum against float64, every
+    padding mode, centre off, a short window, ragged frame counts; and against the whole-row
+    engine the size ran on before (plan option wave_fft = 0)."""
+    from mlx_audio_amd import _lib
+    from mlx_audio_amd._runtime import get_plan
+    from mlx_audio_amd.primitives import stft
+    from mlx_audio_amd.primitives.windows import padded_window_np
+
+    hop = max(1, n_fft // 4)
+    g = torch.Generator(device=gpu).manual_seed(n_fft)
+    y = torch.randn((3, 11 * n_fft + 5), device=gpu, generator=g)
+    y[1, : 3 * n_fft] *= 1e-3
+    win = torch.hann_window(n_fft, periodic=True, dtype=torch.float64, device=gpu)
+    for pad_mode in ("reflect", "constant"):
+        got = stft(y, n_fft=n_fft, hop_length=hop, pad_mode=pad_mode)
+        ref = torch.stft(y.double(), n_fft, hop_length=hop, window=win, center=True, pad_mode=pad_mode,
+                         return_complex=True)
+        assert got.shape == ref.shape
+        assert float((got - ref).abs().max() / ref.abs().max()) <= 2e-6, pad_mode
+    if n_fft >= 24:
+        got = stft(y, n_fft=n_fft, hop_length=hop + 1, center=False, win_length=n_fft - 3)
+        w2 = torch.zeros(n_fft, dtype=torch.float64, device=gpu)
+        lo = (n_fft - (n_fft - 3)) // 2
+        w2[lo: lo + n_fft - 3] = torch.hann_window(n_fft - 3, periodic=True, dtype=torch.float64, device=gpu)
+        ref = torch.stft(y.double(), n_fft, hop_length=hop + 1, window=w2, center=False, return_complex=True)
+        assert float((got - ref).abs().max() / ref.abs().max()) <= 2e-6
+    # the same plan on the whole-row engine
+    lib = _lib.lib()
+    plan = get_plan(y.device, n_fft, hop, True, "edge", padded_window_np("hann", n_fft, n_fft))
+    a = stft(y, n_fft=n_fft, hop_length=hop, pad_mode="edge")
+    try:
+        _lib.check(lib.mia_plan_set_option(plan.handle, b"wave_fft", 0))
+        assert lib.mia_stft_workspace_bytes(plan.handle, 3, y.shape[1]) > 0
+        b = stft(y, n_fft=n_fft, hop_length=hop, pad_mode="edge")
+    finally:
+        lib.mia_plan_set_option(plan.handle, b"wave_fft", 1)
+    assert float((a - b).abs().max() / b.abs().max()) <= 3e-6
 
 
 @pytest.mark.parametrize("n_fft,hop", [(1024, 256), (2048, 512), (4096, 1024), (512, 128), (400, 160)])
