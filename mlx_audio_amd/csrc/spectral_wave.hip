@@ -19,7 +19,7 @@
 namespace mia {
 namespace wavefft {
 
-constexpr int WG = 256, WAVES = WG / 64, FPW = 2, FT = WAVES * FPW;
+constexpr int WG = 256, WAVES = WG / 64, MAXFPW = 2;  // frames per wave and tile: 1 or 2
 constexpr int MAXP = 6, MAXM = 1024;
 
 struct Passes {
@@ -63,9 +63,13 @@ __device__ __forceinline__ void pass(const float2* __restrict__ src, float2* __r
   }
 }
 
+#ifndef MIA_WAVE_OCC
+#define MIA_WAVE_OCC 3
+#endif
 template <int MODE>  // 0: spectrum rows, 1: mel (B, n_mels, F), 3: mel (B, F, n_mels)
-__global__ __launch_bounds__(WG) void fwd_wave_kernel(FwdParams p, Passes ps, int M) {
+__global__ __launch_bounds__(WG, MIA_WAVE_OCC) void fwd_wave_kernel(FwdParams p, Passes ps, int M, int FPW) {
   constexpr bool MEL = MODE != 0;
+  const int FT = WAVES * FPW;  // frames per tile
   const int N = 2 * M;
   const int LB = buf_len(M);
   const int PS = (M + 1) | 1;  // odd row stride of the power tile
@@ -200,8 +204,8 @@ __global__ __launch_bounds__(WG) void fwd_wave_kernel(FwdParams p, Passes ps, in
       float* const stage = reinterpret_cast<float*>(bufs);  // frame-major rows leave through the idle FFT buffers
       auto project = [&](const int* row_lo, const int* row_len, const int* row_off, const float* wts) {
         for (int idx2 = tid; idx2 < p.n_mels * FT; idx2 += WG) {
-          const int m = idx2 / FT;
-          const int fl = idx2 - m * FT;
+          const int m = idx2 >> (FPW == 2 ? 3 : 2);  // FT = 8 or 4
+          const int fl = idx2 & (FT - 1);
           if (fl >= fcount) continue;
           const int lo = row_lo[m], len = row_len[m];
           const float* w = wts + row_off[m];
@@ -269,10 +273,10 @@ __global__ __launch_bounds__(WG) void fwd_wave_kernel(FwdParams p, Passes ps, in
   }
 }
 
-static size_t lds_bytes(int M, int mode, int n_mels, int nnz, bool with_tables) {
+static size_t lds_bytes(int M, int mode, int n_mels, int nnz, bool with_tables, int fpw) {
   size_t b = sizeof(float2) * ((size_t)WAVES * 2 * buf_len(M) + M);
   if (mode != 0) {
-    b += sizeof(float) * (size_t)FT * ((M + 1) | 1);
+    b += sizeof(float) * (size_t)(WAVES * fpw) * ((M + 1) | 1);
     if (with_tables) b += sizeof(float) * (size_t)nnz + 3 * sizeof(int) * (size_t)n_mels;
   }
   return b;
@@ -280,38 +284,72 @@ static size_t lds_bytes(int M, int mode, int n_mels, int nnz, bool with_tables) 
 
 }  // namespace wavefft
 
-// The butterflies of the plan for n_fft (largest first), or false: odd n_fft, a half length above
-// 1024, a prime factor above 7 or more than six passes.
+// The butterflies of the plan for n_fft, or false: odd n_fft, a half length above 1024, a prime
+// factor above 7 or more than six passes.  Among the ordered factorisations into radices 2 .. 16
+// the cheapest by a count of wave instructions: a pass of radix R costs its 64-lane rounds
+// (butterflies / 64, rounded up - a radix above M / 64 leaves lanes idle) times the instructions
+// of one round (loads, twiddle products and stores per point plus the butterfly itself); the
+// first pass has no twiddles, so the largest radix goes first.
 bool forward_wave_plan(int n_fft, int* n_pass, int radix[6]) {
   using namespace wavefft;
   if (n_fft < 4 || n_fft % 2 != 0 || n_fft / 2 > MAXM) return false;
   static const int allowed[] = {16, 15, 12, 10, 8, 7, 6, 5, 4, 3, 2};
-  int rem = n_fft / 2, n = 0;
-  while (rem > 1) {
-    int pick = 0;
-    for (int r : allowed) {
-      if (rem % r == 0) {
-        pick = r;
-        break;
-      }
+  static const int bfly[] = {170, 220, 110, 100, 60, 90, 45, 40, 16, 16, 4};  // instructions of Dft<R>
+  const int M = n_fft / 2;
+  int best[MAXP], best_n = 0, cur[MAXP];
+  long best_cost = -1;
+  // depth-first over non-increasing radix sequences (the order of the passes does not change the cost)
+  struct Frame { int rem, depth, start; };
+  auto cost_of = [&](int n) {
+    long c = 0;
+    for (int i = 0; i < n; ++i) {
+      int a = 0;
+      while (allowed[a] != cur[i]) ++a;
+      const int rounds = (M / cur[i] + 63) / 64;
+      c += (long)rounds * ((i == 0 ? 6 : 10) * cur[i] + bfly[a]) + 12;  // + per-pass set-up and sync
     }
-    if (pick == 0 || n == MAXP) return false;
-    radix[n++] = pick;
-    rem /= pick;
+    return c;
+  };
+  // small search space (M <= 1024): plain recursion through an explicit stack
+  int idx[MAXP + 1] = {0};
+  int rem[MAXP + 1];
+  rem[0] = M;
+  int d = 0;
+  while (d >= 0) {
+    if (rem[d] == 1) {
+      const long c = cost_of(d);
+      if (d >= 1 && (best_cost < 0 || c < best_cost)) {
+        best_cost = c;
+        best_n = d;
+        for (int i = 0; i < d; ++i) best[i] = cur[i];
+      }
+      --d;
+      continue;
+    }
+    if (d == MAXP || idx[d] >= (int)(sizeof(allowed) / sizeof(allowed[0]))) {
+      --d;
+      continue;
+    }
+    const int a = idx[d]++;
+    if (rem[d] % allowed[a] != 0) continue;
+    cur[d] = allowed[a];
+    rem[d + 1] = rem[d] / allowed[a];
+    idx[d + 1] = a;  // non-increasing
+    ++d;
   }
-  *n_pass = n;
-  return n >= 1;
+  if (best_cost < 0) return false;
+  for (int i = 0; i < best_n; ++i) radix[i] = best[i];
+  *n_pass = best_n;
+  return true;
 }
 
-// Mel modes keep eight power rows beside the buffers: they fit for every size the plan covers;
-// frame-major rows additionally leave through the FFT buffers.
+// Frame-major rows leave through the FFT buffers (a tile's n_mels x frames values fit them for
+// every size the plan covers unless n_mels is very large).
 bool forward_wave_frame_major_ok(int n_fft, int n_mels) {
   using namespace wavefft;
-  return n_mels % 4 == 0 &&
-         sizeof(float) * (size_t)FT * n_mels <= sizeof(float2) * (size_t)WAVES * 2 * buf_len(n_fft / 2);
+  return n_mels % 4 == 0 && sizeof(float) * (size_t)(WAVES * MAXFPW) * n_mels <=
+                                sizeof(float2) * (size_t)WAVES * 2 * buf_len(n_fft / 2);
 }
-
-int forward_wave_tile_frames() { return wavefft::FT; }
 
 int launch_forward_wave(const mia_plan* plan, const FwdParams& p0, int mode, hipStream_t s) {
   using namespace wavefft;
@@ -327,6 +365,14 @@ int launch_forward_wave(const mia_plan* plan, const FwdParams& p0, int mode, hip
     set_error("frame-major mel rows do not fit this plan's FFT buffers");
     return MIA_ERR_UNSUPPORTED;
   }
+  // Frames per wave and tile: two (a tile of eight frames: 32-byte runs of a mel row), or one
+  // where that lets a second workgroup onto the CU (long transforms with a power tile).
+  int fpw = MAXFPW;
+  if (kmode != 0 && lds_bytes(M, kmode, p.n_mels, p.nnz, false, 2) > 80 * 1024 &&
+      lds_bytes(M, kmode, p.n_mels, p.nnz, false, 1) <= 80 * 1024) {
+    fpw = 1;
+  }
+  const int FT = WAVES * fpw;
   p.tiles = (int)((p.F + FT - 1) / FT);
   const long long total = p.B * p.tiles;
   if (total <= 0) return MIA_OK;
@@ -334,10 +380,10 @@ int launch_forward_wave(const mia_plan* plan, const FwdParams& p0, int mode, hip
     set_error("%lld tiles do not fit one launch (split the batch)", total);
     return MIA_ERR_UNSUPPORTED;
   }
-  size_t lds = lds_bytes(M, kmode, p.n_mels, p.nnz, false);
+  size_t lds = lds_bytes(M, kmode, p.n_mels, p.nnz, false, fpw);
   p.lds_tables = 0;
-  if (kmode != 0 && lds_bytes(M, kmode, p.n_mels, p.nnz, true) <= 80 * 1024) {
-    lds = lds_bytes(M, kmode, p.n_mels, p.nnz, true);  // band tables ride along while two workgroups fit a CU
+  if (kmode != 0 && lds_bytes(M, kmode, p.n_mels, p.nnz, true, fpw) <= 80 * 1024) {
+    lds = lds_bytes(M, kmode, p.n_mels, p.nnz, true, fpw);  // band tables ride along while two workgroups fit a CU
     p.lds_tables = 1;
   }
   if (lds > 160 * 1024) {
@@ -363,7 +409,7 @@ int launch_forward_wave(const mia_plan* plan, const FwdParams& p0, int mode, hip
   }
   p.tiles_per_wg = (int)per_wg;
   grid = (total + per_wg - 1) / per_wg;
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WG), lds, s, p, ps, M);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WG), lds, s, p, ps, M, fpw);
   MIA_CHECK_HIP(hipGetLastError());
   return MIA_OK;
 }
