@@ -102,7 +102,7 @@ struct mia_plan {
   // any-length plan (n_fft without a compiled LDS kernel): whole-row engine of bigfft.hip
   int generic = 0;
   int wave_fft = 0;              // ... whose forward transform (spectrum and mel modes) the per-wave kernel of
-                                 // spectral_wave.hip serves without a workspace (even n_fft <= 2048, 7-smooth)
+                                 // spectral_wave.hip serves without a workspace (7-smooth: even n_fft <= 2048, odd <= 1023)
   float2* d_chirp = nullptr;     // chirp-z path only: exp(i pi n^2 / n_fft)
   float2* d_bspec = nullptr;     // ... and the spectrum of the convolution kernel
   int opt_table_sweep = 0;       // mia_plan_set_option("w400_table_sweep"): ablation / test knob

@@ -1,6 +1,7 @@
 // Forward transform for the n_fft that have no compiled plan: any even n_fft up to 2048 whose
 // half length factors into butterflies of at most 16 points (2^a 3^b 5^c 7^d: 320, 480, 640,
-// 882, 960, 1200, 1536, 1764, ...).  The reference takes any n_fft at one speed (mx.fft.rfft,
+// 882, 960, 1200, 1536, 1764, ...), and any such odd n_fft up to 1023 (441, 675, 945: transformed
+// unpacked, with zero imaginary parts).  The reference takes any n_fft at one speed (mx.fft.rfft,
 // primitives/stft.py:109-133); the whole-row engine of bigfft.hip, which served these sizes
 // alone before, gathers the frames into a workspace and makes several trips through memory
 // (64 x 30 s at n_fft 960: 3.9 ms against 0.15 ms for the compiled 1024-point plan).
@@ -67,12 +68,16 @@ __device__ __forceinline__ void pass(const float2* __restrict__ src, float2* __r
 #define MIA_WAVE_OCC 3
 #endif
 template <int MODE>  // 0: spectrum rows, 1: mel (B, n_mels, F), 3: mel (B, F, n_mels)
-__global__ __launch_bounds__(WG, MIA_WAVE_OCC) void fwd_wave_kernel(FwdParams p, Passes ps, int M, int FPW) {
+__global__ __launch_bounds__(WG, MIA_WAVE_OCC) void fwd_wave_kernel(FwdParams p, Passes ps, int M, int FPW,
+                                                                    int packed) {
+  // packed: n_fft is even, M = n_fft / 2 points z[n] = x[2 n] + i x[2 n + 1] and a split step;
+  // else n_fft is odd, M = n_fft points with zero imaginary parts, bins 0 .. (M - 1) / 2 as they come
   constexpr bool MEL = MODE != 0;
   const int FT = WAVES * FPW;  // frames per tile
-  const int N = 2 * M;
+  const int N = packed ? 2 * M : M;
+  const int BINS = N / 2 + 1;
   const int LB = buf_len(M);
-  const int PS = (M + 1) | 1;  // odd row stride of the power tile
+  const int PS = BINS | 1;  // odd row stride of the power tile
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float2* const bufs = reinterpret_cast<float2*>(smem_raw);      // [WAVES][2][LB]
   float2* const twM = bufs + WAVES * 2 * LB;                      // [M]
@@ -82,7 +87,7 @@ __global__ __launch_bounds__(WG, MIA_WAVE_OCC) void fwd_wave_kernel(FwdParams p,
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  for (int k = tid; k < M; k += WG) twM[k] = p.tw[2 * k];
+  for (int k = tid; k < M; k += WG) twM[k] = p.tw[packed ? 2 * k : k];
   if constexpr (MEL) {
     if (p.lds_tables) {
       for (int i = tid; i < p.nnz; i += WG) lds_wts[i] = p.wts[i];
@@ -116,7 +121,12 @@ __global__ __launch_bounds__(WG, MIA_WAVE_OCC) void fwd_wave_kernel(FwdParams p,
       // ---- windowed sample pairs z[n] = x[2 n] + i x[2 n + 1] --------------------------------
       const long long s0 = f * p.hop - p.pad;
       const bool interior = s0 >= 0 && s0 + N <= p.T;
-      if (interior && (reinterpret_cast<uintptr_t>(yb + s0) & 7) == 0) {
+      if (!packed) {
+        for (int n = lane; n < M; n += 64) {
+          const float x = interior ? yb[s0 + n] : fetch_sample(yb, p.T, s0 + n, p.pad_mode);
+          bufA[pos(n)] = {x * p.win[n], 0.0f};
+        }
+      } else if (interior && (reinterpret_cast<uintptr_t>(yb + s0) & 7) == 0) {
         const float2* __restrict__ src = reinterpret_cast<const float2*>(yb + s0);
         for (int n = lane; n < M; n += 64) {
           const float2 x = src[n], w = win2[n];
@@ -163,9 +173,19 @@ __global__ __launch_bounds__(WG, MIA_WAVE_OCC) void fwd_wave_kernel(FwdParams p,
       }
       // ---- split step: bins k and M - k from Z[k] and Z[M - k] --------------------------------
       // E = U + conj(V);  O = -i (U - conj(V));  X[k] = (E + w O) / 2,  X[M - k] = conj(E - w O) / 2
-      float2* __restrict__ crow = MODE == 0 ? p.cout + (b * p.F + f) * (long long)(M + 1) : nullptr;
+      float2* __restrict__ crow = MODE == 0 ? p.cout + (b * p.F + f) * (long long)BINS : nullptr;
       float* __restrict__ prow = P + fl * PS;
-      for (int k = lane; 2 * k <= M; k += 64) {
+      if (!packed) {  // the transform of the real frame itself: its first half is the spectrum
+        for (int k = lane; k < BINS; k += 64) {
+          const float2 X = src[pos(k)];
+          if constexpr (MODE == 0) {
+            crow[k] = {X.x * p.scale, X.y * p.scale};
+          } else {
+            prow[k] = X.x * X.x + X.y * X.y;
+          }
+        }
+      }
+      for (int k = lane; packed && 2 * k <= M; k += 64) {
         const float2 U = src[pos(k)];
         const float2 V = src[pos(k == 0 ? 0 : M - k)];
         const float2 w = p.tw[k];
@@ -192,7 +212,7 @@ __global__ __launch_bounds__(WG, MIA_WAVE_OCC) void fwd_wave_kernel(FwdParams p,
       if (p.power_mode != 0) {  // magnitudes or |X|^p instead of powers
         for (int i = tid; i < fcount * PS; i += WG) {
           const int k = i % PS;
-          if (k <= M) {
+          if (k < BINS) {
             const float mag = sqrtf(P[i]);
             P[i] = p.power_mode == 1 ? mag : powf(mag, p.power);
           }
@@ -273,10 +293,10 @@ __global__ __launch_bounds__(WG, MIA_WAVE_OCC) void fwd_wave_kernel(FwdParams p,
   }
 }
 
-static size_t lds_bytes(int M, int mode, int n_mels, int nnz, bool with_tables, int fpw) {
+static size_t lds_bytes(int M, int bins, int mode, int n_mels, int nnz, bool with_tables, int fpw) {
   size_t b = sizeof(float2) * ((size_t)WAVES * 2 * buf_len(M) + M);
   if (mode != 0) {
-    b += sizeof(float) * (size_t)(WAVES * fpw) * ((M + 1) | 1);
+    b += sizeof(float) * (size_t)(WAVES * fpw) * (bins | 1);
     if (with_tables) b += sizeof(float) * (size_t)nnz + 3 * sizeof(int) * (size_t)n_mels;
   }
   return b;
@@ -292,10 +312,10 @@ static size_t lds_bytes(int M, int mode, int n_mels, int nnz, bool with_tables, 
 // first pass has no twiddles, so the largest radix goes first.
 bool forward_wave_plan(int n_fft, int* n_pass, int radix[6]) {
   using namespace wavefft;
-  if (n_fft < 4 || n_fft % 2 != 0 || n_fft / 2 > MAXM) return false;
+  if (n_fft < 3 || (n_fft % 2 == 0 ? n_fft / 2 : n_fft) > MAXM) return false;
   static const int allowed[] = {16, 15, 12, 10, 8, 7, 6, 5, 4, 3, 2};
   static const int bfly[] = {170, 220, 110, 100, 60, 90, 45, 40, 16, 16, 4};  // instructions of Dft<R>
-  const int M = n_fft / 2;
+  const int M = n_fft % 2 == 0 ? n_fft / 2 : n_fft;  // an odd n_fft is transformed unpacked
   int best[MAXP], best_n = 0, cur[MAXP];
   long best_cost = -1;
   // depth-first over non-increasing radix sequences (the order of the passes does not change the cost)
@@ -348,7 +368,7 @@ bool forward_wave_plan(int n_fft, int* n_pass, int radix[6]) {
 bool forward_wave_frame_major_ok(int n_fft, int n_mels) {
   using namespace wavefft;
   return n_mels % 4 == 0 && sizeof(float) * (size_t)(WAVES * MAXFPW) * n_mels <=
-                                sizeof(float2) * (size_t)WAVES * 2 * buf_len(n_fft / 2);
+                                sizeof(float2) * (size_t)WAVES * 2 * buf_len(n_fft % 2 == 0 ? n_fft / 2 : n_fft);
 }
 
 int launch_forward_wave(const mia_plan* plan, const FwdParams& p0, int mode, hipStream_t s) {
@@ -358,7 +378,9 @@ int launch_forward_wave(const mia_plan* plan, const FwdParams& p0, int mode, hip
     set_error("n_fft=%d is not served by the per-wave transform", plan->n_fft);
     return MIA_ERR_UNSUPPORTED;
   }
-  const int M = plan->n_fft / 2;
+  const int packed = plan->n_fft % 2 == 0 ? 1 : 0;
+  const int M = packed ? plan->n_fft / 2 : plan->n_fft;
+  const int bins = plan->n_fft / 2 + 1;
   FwdParams p = p0;
   const int kmode = mode == 0 ? 0 : (p.frame_major ? 3 : 1);
   if (kmode == 3 && !forward_wave_frame_major_ok(plan->n_fft, p.n_mels)) {
@@ -368,8 +390,8 @@ int launch_forward_wave(const mia_plan* plan, const FwdParams& p0, int mode, hip
   // Frames per wave and tile: two (a tile of eight frames: 32-byte runs of a mel row), or one
   // where that lets a second workgroup onto the CU (long transforms with a power tile).
   int fpw = MAXFPW;
-  if (kmode != 0 && lds_bytes(M, kmode, p.n_mels, p.nnz, false, 2) > 80 * 1024 &&
-      lds_bytes(M, kmode, p.n_mels, p.nnz, false, 1) <= 80 * 1024) {
+  if (kmode != 0 && lds_bytes(M, bins, kmode, p.n_mels, p.nnz, false, 2) > 80 * 1024 &&
+      lds_bytes(M, bins, kmode, p.n_mels, p.nnz, false, 1) <= 80 * 1024) {
     fpw = 1;
   }
   const int FT = WAVES * fpw;
@@ -380,10 +402,10 @@ int launch_forward_wave(const mia_plan* plan, const FwdParams& p0, int mode, hip
     set_error("%lld tiles do not fit one launch (split the batch)", total);
     return MIA_ERR_UNSUPPORTED;
   }
-  size_t lds = lds_bytes(M, kmode, p.n_mels, p.nnz, false, fpw);
+  size_t lds = lds_bytes(M, bins, kmode, p.n_mels, p.nnz, false, fpw);
   p.lds_tables = 0;
-  if (kmode != 0 && lds_bytes(M, kmode, p.n_mels, p.nnz, true, fpw) <= 80 * 1024) {
-    lds = lds_bytes(M, kmode, p.n_mels, p.nnz, true, fpw);  // band tables ride along while two workgroups fit a CU
+  if (kmode != 0 && lds_bytes(M, bins, kmode, p.n_mels, p.nnz, true, fpw) <= 80 * 1024) {
+    lds = lds_bytes(M, bins, kmode, p.n_mels, p.nnz, true, fpw);  // band tables ride along while two workgroups fit a CU
     p.lds_tables = 1;
   }
   if (lds > 160 * 1024) {
@@ -409,7 +431,7 @@ int launch_forward_wave(const mia_plan* plan, const FwdParams& p0, int mode, hip
   }
   p.tiles_per_wg = (int)per_wg;
   grid = (total + per_wg - 1) / per_wg;
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WG), lds, s, p, ps, M, fpw);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WG), lds, s, p, ps, M, fpw, packed);
   MIA_CHECK_HIP(hipGetLastError());
   return MIA_OK;
 }

@@ -331,16 +331,16 @@ def test_any_length_plans_reject_the_entry_points_without_workspace(gpu):
     from mlx_audio_amd.primitives.windows import padded_window_np
 
     lib = _lib.lib()
-    assert lib.mia_fft_size_supported(441) == 0 and lib.mia_fft_size_supported(400) == 1
-    # an odd n_fft runs on the whole-row engine, which needs its workspace
-    plan = get_plan(gpu, 441, 110, True, "constant", padded_window_np("hann", 441, 441))
+    assert lib.mia_fft_size_supported(422) == 0 and lib.mia_fft_size_supported(400) == 1
+    # a size with a large prime factor (422 = 2 x 211) runs on the whole-row engine, which needs its workspace
+    plan = get_plan(gpu, 422, 110, True, "constant", padded_window_np("hann", 422, 422))
     y = torch.zeros((1, 2000), device=gpu)
-    out = torch.empty((1, plan.num_frames(2000), 221), dtype=torch.complex64, device=gpu)
+    out = torch.empty((1, plan.num_frames(2000), 212), dtype=torch.complex64, device=gpu)
     assert lib.mia_stft_workspace_bytes(plan.handle, 1, 2000) > 0
     rc = lib.mia_stft(plan.handle, y.data_ptr(), 1, 2000, 1.0, out.data_ptr(), None)
     assert rc == _lib.MIA_ERR_INVALID and b"mia_stft_ws" in lib.mia_last_error()
-    # an even 7-smooth n_fft up to 2048 has no compiled plan either but is served by the per-wave
-    # kernel: no workspace, the plain entry point works
+    # a 7-smooth n_fft (even up to 2048, odd up to 1023) has no compiled plan either but is served by
+    # the per-wave kernel: no workspace, the plain entry point works
     plan = get_plan(gpu, 300, 75, True, "constant", padded_window_np("hann", 300, 300))
     assert lib.mia_fft_size_supported(300) == 0
     assert lib.mia_stft_workspace_bytes(plan.handle, 1, 1000) == 0
@@ -351,13 +351,14 @@ def test_any_length_plans_reject_the_entry_points_without_workspace(gpu):
     assert float(out.abs().max()) == 0.0
 
 
-WAVE_SIZES = [4, 6, 24, 98, 300, 320, 480, 640, 882, 960, 1200, 1536, 1764, 2000, 2016, 2048 - 2 * 7]
+WAVE_SIZES = [4, 6, 24, 98, 300, 320, 480, 640, 882, 960, 1200, 1536, 1764, 2000, 2016, 2048 - 2 * 7,
+              3, 9, 105, 441, 675, 945]  # ... and odd sizes, transformed unpacked
 
 
 @pytest.mark.parametrize("n_fft", WAVE_SIZES)
 def test_per_wave_transform_sizes(gpu, n_fft):
-    """Even n_fft up to 2048 with a 7-smooth half length (radices 2 ... 16 in every mix: 882 =
-    2 (7 7 3 3), 960 = 2 (16 15 2), 2000 = 2 (10 10 10), ...): spectrum against float64, every
+    """n_fft with 7-smooth (half) lengths, even up to 2048 and odd up to 1023 (radices 2 ... 16 in
+    every mix: 882 = 2 (7 7 3 3), 960 = 2 (12 10 4), 2000 = 2 (10 10 10), 441 = 7 7 3 3, 945 = 7 5 3 3 3): spectrum against float64, every
     padding mode, centre off, a short window, ragged frame counts; and against the whole-row
     engine the size ran on before (plan option wave_fft = 0)."""
     from mlx_audio_amd import _lib
