@@ -720,7 +720,7 @@ int mia_irfft_frames(const mia_plan* plan, const void* spec, int64_t B, int64_t 
   MIA_REQUIRE(plan != nullptr, "null plan");
   MIA_REQUIRE(B >= 0 && F >= 0, "negative shape");
   MIA_REQUIRE((spec && frames) || B == 0 || F == 0, "null buffer");
-  if (plan->generic) {
+  if (plan->generic && !plan->wave_fft) {
     set_error("n_fft=%d has no compiled kernel: use mia_istft (it takes the workspace the "
               "any-length engine needs)", plan->n_fft);
     return MIA_ERR_UNSUPPORTED;
@@ -734,6 +734,7 @@ int mia_irfft_frames(const mia_plan* plan, const void* spec, int64_t B, int64_t 
   p.sf = stride_frame;
   p.tw = plan->d_tw;
   p.frames = frames;
+  if (plan->wave_fft) return launch_inverse_wave(plan, p, (hipStream_t)stream);
   return launch_inverse(plan, p, (hipStream_t)stream);
 }
 
@@ -755,7 +756,7 @@ int mia_overlap_add(const float* frames, const float* window, int64_t B, int64_t
 
 size_t mia_istft_workspace_bytes(const mia_plan* plan, int64_t B, int64_t F) {
   if (!plan || B <= 0 || F <= 0) return 0;
-  if (plan->generic) {  // frames + the any-length engine's row buffers
+  if (plan->generic && !plan->wave_fft) {  // frames + the any-length engine's row buffers
     return align256(sizeof(float) * (size_t)B * (size_t)F * (size_t)plan->n_fft) +
            generic_fft_bytes(plan->n_fft, B * F);
   }
@@ -767,7 +768,7 @@ int mia_istft(const mia_plan* plan, const void* spec, int64_t B, int64_t F, int6
               int64_t stride_bin, int64_t stride_frame, int64_t out_len, float scale, float* out,
               void* workspace, size_t workspace_bytes, void* stream) {
   MIA_REQUIRE(plan != nullptr, "null plan");
-  if (plan->generic) {
+  if (plan->generic && !plan->wave_fft) {
     MIA_REQUIRE(B >= 0 && F >= 0 && out_len >= 0, "negative shape");
     MIA_REQUIRE((spec && out) || B == 0 || F == 0 || out_len == 0, "null buffer");
     if (B == 0 || out_len == 0) return MIA_OK;

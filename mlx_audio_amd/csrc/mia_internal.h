@@ -229,6 +229,7 @@ int launch_forward_lane(const FwdParams& p, int cus, hipStream_t s);
 bool forward_wave_plan(int n_fft, int* n_pass, int radix[6]);
 bool forward_wave_frame_major_ok(int n_fft, int n_mels);
 int launch_forward_wave(const mia_plan* plan, const FwdParams& p, int mode, hipStream_t s);
+int launch_inverse_wave(const mia_plan* plan, const InvParams& p, hipStream_t s);
 bool dct2_frame_major_ok(int n_in, int n_out);
 int launch_dct2_frame_major(const float* x, long long outer, int n_in, long long inner, const float* basis,
                             int n_out, float* out, const int* keys, long long key_stride, float top,

@@ -293,6 +293,98 @@ __global__ __launch_bounds__(WG, MIA_WAVE_OCC) void fwd_wave_kernel(FwdParams p,
   }
 }
 
+// The inverse: bins of one frame -> n_fft real samples (scaled by 1 / n_fft) in the frame
+// workspace the overlap-add kernel reads, a frame per wave.  The inverse transform runs as the
+// forward one on conjugated input (sum_k Z[k] e^{+2 pi i k n / M} = conj(FFT(conj Z))[n]); for
+// an even n_fft the bins are first folded into the half-length sequence Z[k] = E + i O,
+// E = (X[k] + conj X[M - k]) / 2, O = conj(w_k) (X[k] - conj X[M - k]) / 2, the inverse of the
+// forward kernel's split step; the imaginary parts of X[0] and X[n_fft / 2] are ignored, as
+// they are by the compiled plans.
+__global__ __launch_bounds__(WG, MIA_WAVE_OCC) void inv_wave_kernel(InvParams p, Passes ps, int M, int packed,
+                                                                    long long frames_per_wg) {
+  const int N = packed ? 2 * M : M;
+  const int LB = buf_len(M);
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float2* const bufs = reinterpret_cast<float2*>(smem_raw);  // [WAVES][2][LB]
+  float2* const twM = bufs + WAVES * 2 * LB;                  // [M]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int k = tid; k < M; k += WG) twM[k] = p.tw[packed ? 2 * k : k];
+  __syncthreads();
+  float2* const bufA = bufs + wave * 2 * LB;
+  float2* const bufB = bufA + LB;
+  const long long total = p.B * p.F;
+  const long long first = (long long)blockIdx.x * frames_per_wg;
+  const long long last = first + frames_per_wg < total ? first + frames_per_wg : total;
+  const float inv_n = 1.0f / (float)N;
+  for (long long fi = first + wave; fi < last; fi += WAVES) {
+    const long long b = fi / p.F, f = fi - b * p.F;
+    const float2* __restrict__ xs = p.spec + b * p.sb + f * p.sf;
+    if (packed) {
+      for (int k = lane; 2 * k <= M; k += 64) {
+        float2 xk = xs[(long long)k * p.sk], xm = xs[(long long)(M - k) * p.sk];
+        if (k == 0) {
+          xk.y = 0.0f;
+          xm.y = 0.0f;
+        }
+        const float2 w = p.tw[k];
+        const float2 E = {xk.x + xm.x, xk.y - xm.y};
+        const float2 D = {xk.x - xm.x, xk.y + xm.y};
+        const float2 O = {D.x * w.x + D.y * w.y, D.y * w.x - D.x * w.y};  // D conj(w)
+        // twice Z[k] and Z[M - k]; stored conjugated for the forward passes
+        bufA[pos(k)] = {E.x - O.y, -(E.y + O.x)};
+        if (k != 0 && 2 * k != M) bufA[pos(M - k)] = {E.x + O.y, E.y - O.x};
+      }
+    } else {
+      for (int k = lane; 2 * k <= M; k += 64) {  // Hermitian extension of bins 0 .. (M - 1) / 2
+        const float2 x = xs[(long long)k * p.sk];
+        if (k == 0) {
+          bufA[pos(0)] = {x.x, 0.0f};
+        } else {
+          bufA[pos(k)] = {x.x, -x.y};
+          bufA[pos(M - k)] = {x.x, x.y};
+        }
+      }
+    }
+    wave_sync();
+    const float2* src = bufA;
+    float2* dst = bufB;
+    int NS = 1;
+    for (int pi = 0; pi < ps.n; ++pi) {
+      const int R = ps.radix[pi];
+      const float inv_ns = 1.0f / (float)NS;
+      switch (R) {
+        case 2: pass<2>(src, dst, twM, M, NS, inv_ns, lane); break;
+        case 3: pass<3>(src, dst, twM, M, NS, inv_ns, lane); break;
+        case 4: pass<4>(src, dst, twM, M, NS, inv_ns, lane); break;
+        case 5: pass<5>(src, dst, twM, M, NS, inv_ns, lane); break;
+        case 6: pass<6>(src, dst, twM, M, NS, inv_ns, lane); break;
+        case 7: pass<7>(src, dst, twM, M, NS, inv_ns, lane); break;
+        case 8: pass<8>(src, dst, twM, M, NS, inv_ns, lane); break;
+        case 10: pass<10>(src, dst, twM, M, NS, inv_ns, lane); break;
+        case 12: pass<12>(src, dst, twM, M, NS, inv_ns, lane); break;
+        case 15: pass<15>(src, dst, twM, M, NS, inv_ns, lane); break;
+        default: pass<16>(src, dst, twM, M, NS, inv_ns, lane); break;
+      }
+      wave_sync();
+      float2* const t = const_cast<float2*>(src);
+      src = dst;
+      dst = t;
+      NS *= R;
+    }
+    float* __restrict__ orow = p.frames + fi * (long long)N;
+    if (packed) {  // (x[2 n], x[2 n + 1]) = conj(y[n]) / (2 M): the sequence above was twice Z
+      for (int n = lane; n < M; n += 64) {
+        const float2 y = src[pos(n)];
+        reinterpret_cast<float2*>(orow)[n] = {y.x * inv_n, -y.y * inv_n};
+      }
+    } else {
+      for (int n = lane; n < M; n += 64) orow[n] = src[pos(n)].x * inv_n;
+    }
+    wave_sync();  // the next frame overwrites the buffers
+  }
+}
+
 static size_t lds_bytes(int M, int bins, int mode, int n_mels, int nnz, bool with_tables, int fpw) {
   size_t b = sizeof(float2) * ((size_t)WAVES * 2 * buf_len(M) + M);
   if (mode != 0) {
@@ -432,6 +524,38 @@ int launch_forward_wave(const mia_plan* plan, const FwdParams& p0, int mode, hip
   p.tiles_per_wg = (int)per_wg;
   grid = (total + per_wg - 1) / per_wg;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WG), lds, s, p, ps, M, fpw, packed);
+  MIA_CHECK_HIP(hipGetLastError());
+  return MIA_OK;
+}
+
+int launch_inverse_wave(const mia_plan* plan, const InvParams& p, hipStream_t s) {
+  using namespace wavefft;
+  Passes ps{};
+  if (!forward_wave_plan(plan->n_fft, &ps.n, ps.radix)) {
+    set_error("n_fft=%d is not served by the per-wave transform", plan->n_fft);
+    return MIA_ERR_UNSUPPORTED;
+  }
+  const int packed = plan->n_fft % 2 == 0 ? 1 : 0;
+  const int M = packed ? plan->n_fft / 2 : plan->n_fft;
+  const long long total = p.B * p.F;
+  if (total <= 0) return MIA_OK;
+  const size_t lds = sizeof(float2) * ((size_t)WAVES * 2 * buf_len(M) + M);
+  auto kern = inv_wave_kernel;
+  if (lds > 64 * 1024) {
+    MIA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  }
+  int per_cu = 1;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), WG, lds) !=
+          hipSuccess || per_cu < 1) {
+    per_cu = 1;
+  }
+  long long grid = (long long)(plan->cus > 0 ? plan->cus : 256) * per_cu;
+  const long long groups = (total + WAVES - 1) / WAVES;  // a workgroup takes four frames at a time
+  if (grid > groups) grid = groups;
+  const long long per_wg = ((groups + grid - 1) / grid) * WAVES;
+  grid = (total + per_wg - 1) / per_wg;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WG), lds, s, p, ps, M, packed, per_wg);
   MIA_CHECK_HIP(hipGetLastError());
   return MIA_OK;
 }

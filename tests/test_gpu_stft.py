@@ -384,17 +384,27 @@ def test_per_wave_transform_sizes(gpu, n_fft):
         w2[lo: lo + n_fft - 3] = torch.hann_window(n_fft - 3, periodic=True, dtype=torch.float64, device=gpu)
         ref = torch.stft(y.double(), n_fft, hop_length=hop + 1, window=w2, center=False, return_complex=True)
         assert float((got - ref).abs().max() / ref.abs().max()) <= 2e-6
-    # the same plan on the whole-row engine
+    # the same plan on the whole-row engine, forward and inverse
+    from mlx_audio_amd.primitives import istft
+
     lib = _lib.lib()
     plan = get_plan(y.device, n_fft, hop, True, "edge", padded_window_np("hann", n_fft, n_fft))
     a = stft(y, n_fft=n_fft, hop_length=hop, pad_mode="edge")
+    xa = istft(a, hop_length=hop, n_fft=n_fft, length=y.shape[1]) if n_fft >= 24 else None
     try:
         _lib.check(lib.mia_plan_set_option(plan.handle, b"wave_fft", 0))
         assert lib.mia_stft_workspace_bytes(plan.handle, 3, y.shape[1]) > 0
         b = stft(y, n_fft=n_fft, hop_length=hop, pad_mode="edge")
+        xb = istft(a, hop_length=hop, n_fft=n_fft, length=y.shape[1]) if n_fft >= 24 else None
     finally:
         lib.mia_plan_set_option(plan.handle, b"wave_fft", 1)
     assert float((a - b).abs().max() / b.abs().max()) <= 3e-6
+    if xa is not None:  # hann at hop n_fft / 4 (or next to it) inverts; the edges lack overlap
+        assert float((xa - xb).abs().max()) <= 2e-5
+        m = n_fft
+        assert float((xa[:, m:-m] - y[:, m:-m]).abs().max()) <= 3e-5
+        one = istft(a[2], hop_length=hop, n_fft=n_fft, length=y.shape[1])
+        assert torch.equal(one, xa[2])
 
 
 @pytest.mark.parametrize("n_fft,hop", [(1024, 256), (2048, 512), (4096, 1024), (512, 128), (400, 160)])

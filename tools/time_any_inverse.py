@@ -1,0 +1,18 @@
+"""istft at n_fft values without a compiled plan, 64 x 30 s, hop n_fft / 4: ms per call."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from mlx_audio_amd.primitives import istft, stft
+def timed(fn, n=5):
+    for _ in range(2): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+y = 0.1 * torch.randn((64, 16000 * 30), device="cuda")
+for n_fft in (320, 441, 480, 960, 1200, 1536, 422, 1024, 512):
+    hop = n_fft // 4
+    S = stft(y, n_fft=n_fft, hop_length=hop)
+    print(f"n_fft {n_fft:5d}: istft {timed(lambda: istft(S, hop_length=hop, n_fft=n_fft, length=y.shape[1])):8.3f} ms")
