@@ -226,7 +226,7 @@ int forward_tile_frames(int n_fft, int mode);
 bool forward_frame_major_ok(int n_fft, int n_mels);
 bool forward_lane_ok(int n_fft, int hop, int n_mels, int nnz);
 int launch_forward_lane(const FwdParams& p, int cus, hipStream_t s);
-bool forward_wave_plan(int n_fft, int* n_pass, int radix[6]);
+bool forward_wave_plan(int n_fft, int* n_pass, int radix[6], int* lanes_per_frame = nullptr);
 bool forward_wave_frame_major_ok(int n_fft, int n_mels);
 int launch_forward_wave(const mia_plan* plan, const FwdParams& p, int mode, hipStream_t s);
 int launch_inverse_wave(const mia_plan* plan, const InvParams& p, hipStream_t s);

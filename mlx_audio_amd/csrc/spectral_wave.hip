@@ -8,12 +8,15 @@
 //
 // Here a frame belongs to ONE wave: its n_fft / 2 complex points sit in the wave's own two LDS
 // buffers and go through Stockham passes whose radices are run-time data (a switch over the
-// butterfly templates; lanes take butterflies lane, lane + 64, ...), twiddles from a table of
+// butterfly templates; lanes take butterflies lane, lane + L, ...), twiddles from a table of
 // exp(-2 pi i k / (n_fft / 2)) in LDS.  No workgroup barrier stands in the frame loop - LDS
-// operations of one wave complete in order.  Split step, spectrum rows / power tile, band
-// projection and epilogues are those of the compiled plans (spectral_fwd.hip); a workgroup is
-// four waves and a tile eight frames.  Per n log n it runs at a third to a half of the compiled
-// plans' rate, which is what run-time radices and 4 - 12 waves per CU cost.
+// operations of one wave complete in order.  Short transforms share a wave: a frame takes
+// L = 1, 2, ... 64 lanes (the power of two that covers its widest pass), 64 / L frames run side
+// by side in a wave, each in its own buffers - for n_fft 16 or 32 a lane holds a whole frame's
+// butterfly.  Split step, spectrum rows / power tile, band projection and epilogues are those of
+// the compiled plans (spectral_fwd.hip); a workgroup is four waves.  Per n log n it runs at a
+// third to a half of the compiled plans' rate, which is what run-time radices and 4 - 12 waves
+// per CU cost.
 #include "fft_engine.h"
 #include "mia_internal.h"
 
@@ -39,14 +42,15 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-// One Stockham pass of radix R after passes whose radices multiply to NS (inv_ns = 1 / NS).
+// One Stockham pass of radix R after passes whose radices multiply to NS (inv_ns = 1 / NS), by
+// the L lanes of one frame (li = lane within the frame).
 template <int R>
 __device__ __forceinline__ void pass(const float2* __restrict__ src, float2* __restrict__ dst,
                                      const float2* __restrict__ twM, int M, int NS, float inv_ns,
-                                     int lane) {
+                                     int li, int L) {
   const int S = M / R;
   const int tstep = S / NS;  // step in the table of exp(-2 pi i k / M)
-  for (int j = lane; j < S; j += 64) {
+  for (int j = li; j < S; j += L) {
     // j / NS and j mod NS without an integer division: exact for j < 2^20
     const int q = NS == 1 ? j : (int)(((float)j + 0.5f) * inv_ns);
     const int jm = j - q * NS;
@@ -64,29 +68,64 @@ __device__ __forceinline__ void pass(const float2* __restrict__ src, float2* __r
   }
 }
 
+// All passes of one frame, ping-pong between its two buffers; returns the buffer that holds the
+// transform in natural order.  Every lane of the wave calls it (frames side by side).
+__device__ __forceinline__ const float2* transform(float2* bufA, float2* bufB, const float2* __restrict__ twM,
+                                                   const Passes& ps, int M, int li, int L) {
+  const float2* src = bufA;
+  float2* dst = bufB;
+  int NS = 1;
+  for (int pi = 0; pi < ps.n; ++pi) {
+    const int R = ps.radix[pi];
+    const float inv_ns = 1.0f / (float)NS;
+    switch (R) {
+      case 2: pass<2>(src, dst, twM, M, NS, inv_ns, li, L); break;
+      case 3: pass<3>(src, dst, twM, M, NS, inv_ns, li, L); break;
+      case 4: pass<4>(src, dst, twM, M, NS, inv_ns, li, L); break;
+      case 5: pass<5>(src, dst, twM, M, NS, inv_ns, li, L); break;
+      case 6: pass<6>(src, dst, twM, M, NS, inv_ns, li, L); break;
+      case 7: pass<7>(src, dst, twM, M, NS, inv_ns, li, L); break;
+      case 8: pass<8>(src, dst, twM, M, NS, inv_ns, li, L); break;
+      case 10: pass<10>(src, dst, twM, M, NS, inv_ns, li, L); break;
+      case 12: pass<12>(src, dst, twM, M, NS, inv_ns, li, L); break;
+      case 15: pass<15>(src, dst, twM, M, NS, inv_ns, li, L); break;
+      default: pass<16>(src, dst, twM, M, NS, inv_ns, li, L); break;
+    }
+    wave_sync();
+    float2* const t = const_cast<float2*>(src);
+    src = dst;
+    dst = t;
+    NS *= R;
+  }
+  return src;
+}
+
 #ifndef MIA_WAVE_OCC
 #define MIA_WAVE_OCC 3
 #endif
 template <int MODE>  // 0: spectrum rows, 1: mel (B, n_mels, F), 3: mel (B, F, n_mels)
 __global__ __launch_bounds__(WG, MIA_WAVE_OCC) void fwd_wave_kernel(FwdParams p, Passes ps, int M, int FPW,
-                                                                    int packed) {
+                                                                    int packed, int L) {
   // packed: n_fft is even, M = n_fft / 2 points z[n] = x[2 n] + i x[2 n + 1] and a split step;
-  // else n_fft is odd, M = n_fft points with zero imaginary parts, bins 0 .. (M - 1) / 2 as they come
+  // else n_fft is odd, M = n_fft points with zero imaginary parts, bins 0 .. (M - 1) / 2 as they come.
+  // L lanes per frame, GF = 64 / L frames side by side in a wave, FPW such rounds per tile.
   constexpr bool MEL = MODE != 0;
-  const int FT = WAVES * FPW;  // frames per tile
+  const int GF = 64 / L;
+  const int FT = WAVES * FPW * GF;  // frames per tile (a power of two)
   const int N = packed ? 2 * M : M;
   const int BINS = N / 2 + 1;
   const int LB = buf_len(M);
   const int PS = BINS | 1;  // odd row stride of the power tile
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  float2* const bufs = reinterpret_cast<float2*>(smem_raw);      // [WAVES][2][LB]
-  float2* const twM = bufs + WAVES * 2 * LB;                      // [M]
+  float2* const bufs = reinterpret_cast<float2*>(smem_raw);      // [WAVES][GF][2][LB]
+  float2* const twM = bufs + WAVES * GF * 2 * LB;                 // [M]
   float* const P = reinterpret_cast<float*>(twM + M);             // [FT][PS] (mel modes)
   float* const lds_wts = P + (MEL ? FT * PS : 0);
   int* const lds_rows = reinterpret_cast<int*>(lds_wts + (MEL ? p.nnz : 0));
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & (L - 1), g = lane / L;  // lane within the frame, frame of the wave's round
   for (int k = tid; k < M; k += WG) twM[k] = p.tw[packed ? 2 * k : k];
   if constexpr (MEL) {
     if (p.lds_tables) {
@@ -100,7 +139,7 @@ __global__ __launch_bounds__(WG, MIA_WAVE_OCC) void fwd_wave_kernel(FwdParams p,
   }
   __syncthreads();
 
-  float2* const bufA = bufs + wave * 2 * LB;
+  float2* const bufA = bufs + (wave * GF + g) * 2 * LB;
   float2* const bufB = bufA + LB;
   const float2* __restrict__ win2 = reinterpret_cast<const float2*>(p.win);
   const float half_scale = 0.5f * p.scale;
@@ -115,68 +154,46 @@ __global__ __launch_bounds__(WG, MIA_WAVE_OCC) void fwd_wave_kernel(FwdParams p,
     const float* __restrict__ yb = p.y + b * p.T;
 
     for (int i = 0; i < FPW; ++i) {
-      const int fl = wave * FPW + i;
+      const int fl = (wave * FPW + i) * GF + g;
       const long long f = f0 + fl;
-      if (f >= p.F) break;  // wave-uniform
+      if (f0 + (long long)(wave * FPW + i) * GF >= p.F) break;  // wave-uniform: the round has no frame
+      const bool valid = f < p.F;  // per frame (lanes of a frame past the clip's end idle along)
       // ---- windowed sample pairs z[n] = x[2 n] + i x[2 n + 1] --------------------------------
       const long long s0 = f * p.hop - p.pad;
       const bool interior = s0 >= 0 && s0 + N <= p.T;
-      if (!packed) {
-        for (int n = lane; n < M; n += 64) {
+      if (!valid) {
+        // nothing to load: the passes run on whatever the buffers hold, nothing is stored
+      } else if (!packed) {
+        for (int n = li; n < M; n += L) {
           const float x = interior ? yb[s0 + n] : fetch_sample(yb, p.T, s0 + n, p.pad_mode);
           bufA[pos(n)] = {x * p.win[n], 0.0f};
         }
       } else if (interior && (reinterpret_cast<uintptr_t>(yb + s0) & 7) == 0) {
         const float2* __restrict__ src = reinterpret_cast<const float2*>(yb + s0);
-        for (int n = lane; n < M; n += 64) {
+        for (int n = li; n < M; n += L) {
           const float2 x = src[n], w = win2[n];
           bufA[pos(n)] = {x.x * w.x, x.y * w.y};
         }
       } else if (interior) {
-        for (int n = lane; n < M; n += 64) {
+        for (int n = li; n < M; n += L) {
           const float2 w = win2[n];
           bufA[pos(n)] = {yb[s0 + 2 * n] * w.x, yb[s0 + 2 * n + 1] * w.y};
         }
       } else {
-        for (int n = lane; n < M; n += 64) {
+        for (int n = li; n < M; n += L) {
           const float2 w = win2[n];
           bufA[pos(n)] = {fetch_sample(yb, p.T, s0 + 2 * n, p.pad_mode) * w.x,
                           fetch_sample(yb, p.T, s0 + 2 * n + 1, p.pad_mode) * w.y};
         }
       }
       wave_sync();
-      // ---- Stockham passes, ping-pong between the wave's two buffers --------------------------
-      const float2* src = bufA;
-      float2* dst = bufB;
-      int NS = 1;
-      for (int pi = 0; pi < ps.n; ++pi) {
-        const int R = ps.radix[pi];
-        const float inv_ns = 1.0f / (float)NS;
-        switch (R) {
-          case 2: pass<2>(src, dst, twM, M, NS, inv_ns, lane); break;
-          case 3: pass<3>(src, dst, twM, M, NS, inv_ns, lane); break;
-          case 4: pass<4>(src, dst, twM, M, NS, inv_ns, lane); break;
-          case 5: pass<5>(src, dst, twM, M, NS, inv_ns, lane); break;
-          case 6: pass<6>(src, dst, twM, M, NS, inv_ns, lane); break;
-          case 7: pass<7>(src, dst, twM, M, NS, inv_ns, lane); break;
-          case 8: pass<8>(src, dst, twM, M, NS, inv_ns, lane); break;
-          case 10: pass<10>(src, dst, twM, M, NS, inv_ns, lane); break;
-          case 12: pass<12>(src, dst, twM, M, NS, inv_ns, lane); break;
-          case 15: pass<15>(src, dst, twM, M, NS, inv_ns, lane); break;
-          default: pass<16>(src, dst, twM, M, NS, inv_ns, lane); break;
-        }
-        wave_sync();
-        float2* const t = const_cast<float2*>(src);
-        src = dst;
-        dst = t;
-        NS *= R;
-      }
+      const float2* src = transform(bufA, bufB, twM, ps, M, li, L);
       // ---- split step: bins k and M - k from Z[k] and Z[M - k] --------------------------------
       // E = U + conj(V);  O = -i (U - conj(V));  X[k] = (E + w O) / 2,  X[M - k] = conj(E - w O) / 2
       float2* __restrict__ crow = MODE == 0 ? p.cout + (b * p.F + f) * (long long)BINS : nullptr;
       float* __restrict__ prow = P + fl * PS;
-      if (!packed) {  // the transform of the real frame itself: its first half is the spectrum
-        for (int k = lane; k < BINS; k += 64) {
+      if (valid && !packed) {  // the transform of the real frame itself: its first half is the spectrum
+        for (int k = li; k < BINS; k += L) {
           const float2 X = src[pos(k)];
           if constexpr (MODE == 0) {
             crow[k] = {X.x * p.scale, X.y * p.scale};
@@ -185,7 +202,7 @@ __global__ __launch_bounds__(WG, MIA_WAVE_OCC) void fwd_wave_kernel(FwdParams p,
           }
         }
       }
-      for (int k = lane; packed && 2 * k <= M; k += 64) {
+      for (int k = li; valid && packed && 2 * k <= M; k += L) {
         const float2 U = src[pos(k)];
         const float2 V = src[pos(k == 0 ? 0 : M - k)];
         const float2 w = p.tw[k];
@@ -202,7 +219,7 @@ __global__ __launch_bounds__(WG, MIA_WAVE_OCC) void fwd_wave_kernel(FwdParams p,
           if (2 * k != M) prow[M - k] = 0.25f * (X2.x * X2.x + X2.y * X2.y);
         }
       }
-      wave_sync();  // the next frame overwrites the buffers
+      wave_sync();  // the next round overwrites the buffers
     }
 
     if constexpr (MEL) {
@@ -219,12 +236,13 @@ __global__ __launch_bounds__(WG, MIA_WAVE_OCC) void fwd_wave_kernel(FwdParams p,
         }
         __syncthreads();
       }
+      const int ft_shift = 31 - __builtin_clz((unsigned)FT);
       int kmax = kKeyMinusInf;  // integer keys: a NaN value wins the maximum, as in the reference
       float vmin = INFINITY;
       float* const stage = reinterpret_cast<float*>(bufs);  // frame-major rows leave through the idle FFT buffers
       auto project = [&](const int* row_lo, const int* row_len, const int* row_off, const float* wts) {
         for (int idx2 = tid; idx2 < p.n_mels * FT; idx2 += WG) {
-          const int m = idx2 >> (FPW == 2 ? 3 : 2);  // FT = 8 or 4
+          const int m = idx2 >> ft_shift;  // FT is a power of two
           const int fl = idx2 & (FT - 1);
           if (fl >= fcount) continue;
           const int lo = row_lo[m], len = row_len[m];
@@ -301,27 +319,31 @@ __global__ __launch_bounds__(WG, MIA_WAVE_OCC) void fwd_wave_kernel(FwdParams p,
 // forward kernel's split step; the imaginary parts of X[0] and X[n_fft / 2] are ignored, as
 // they are by the compiled plans.
 __global__ __launch_bounds__(WG, MIA_WAVE_OCC) void inv_wave_kernel(InvParams p, Passes ps, int M, int packed,
-                                                                    long long frames_per_wg) {
+                                                                    int L, long long frames_per_wg) {
+  const int GF = 64 / L;
   const int N = packed ? 2 * M : M;
   const int LB = buf_len(M);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  float2* const bufs = reinterpret_cast<float2*>(smem_raw);  // [WAVES][2][LB]
-  float2* const twM = bufs + WAVES * 2 * LB;                  // [M]
+  float2* const bufs = reinterpret_cast<float2*>(smem_raw);  // [WAVES][GF][2][LB]
+  float2* const twM = bufs + WAVES * GF * 2 * LB;             // [M]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & (L - 1), g = lane / L;
   for (int k = tid; k < M; k += WG) twM[k] = p.tw[packed ? 2 * k : k];
   __syncthreads();
-  float2* const bufA = bufs + wave * 2 * LB;
+  float2* const bufA = bufs + (wave * GF + g) * 2 * LB;
   float2* const bufB = bufA + LB;
   const long long total = p.B * p.F;
   const long long first = (long long)blockIdx.x * frames_per_wg;
   const long long last = first + frames_per_wg < total ? first + frames_per_wg : total;
   const float inv_n = 1.0f / (float)N;
-  for (long long fi = first + wave; fi < last; fi += WAVES) {
-    const long long b = fi / p.F, f = fi - b * p.F;
+  for (long long base = first + (long long)wave * GF; base < last; base += WAVES * GF) {
+    const long long fi = base + g;
+    const bool valid = fi < last;
+    const long long b = valid ? fi / p.F : 0, f = valid ? fi - b * p.F : 0;
     const float2* __restrict__ xs = p.spec + b * p.sb + f * p.sf;
-    if (packed) {
-      for (int k = lane; 2 * k <= M; k += 64) {
+    if (valid && packed) {
+      for (int k = li; 2 * k <= M; k += L) {
         float2 xk = xs[(long long)k * p.sk], xm = xs[(long long)(M - k) * p.sk];
         if (k == 0) {
           xk.y = 0.0f;
@@ -335,8 +357,8 @@ __global__ __launch_bounds__(WG, MIA_WAVE_OCC) void inv_wave_kernel(InvParams p,
         bufA[pos(k)] = {E.x - O.y, -(E.y + O.x)};
         if (k != 0 && 2 * k != M) bufA[pos(M - k)] = {E.x + O.y, E.y - O.x};
       }
-    } else {
-      for (int k = lane; 2 * k <= M; k += 64) {  // Hermitian extension of bins 0 .. (M - 1) / 2
+    } else if (valid) {
+      for (int k = li; 2 * k <= M; k += L) {  // Hermitian extension of bins 0 .. (M - 1) / 2
         const float2 x = xs[(long long)k * p.sk];
         if (k == 0) {
           bufA[pos(0)] = {x.x, 0.0f};
@@ -347,48 +369,25 @@ __global__ __launch_bounds__(WG, MIA_WAVE_OCC) void inv_wave_kernel(InvParams p,
       }
     }
     wave_sync();
-    const float2* src = bufA;
-    float2* dst = bufB;
-    int NS = 1;
-    for (int pi = 0; pi < ps.n; ++pi) {
-      const int R = ps.radix[pi];
-      const float inv_ns = 1.0f / (float)NS;
-      switch (R) {
-        case 2: pass<2>(src, dst, twM, M, NS, inv_ns, lane); break;
-        case 3: pass<3>(src, dst, twM, M, NS, inv_ns, lane); break;
-        case 4: pass<4>(src, dst, twM, M, NS, inv_ns, lane); break;
-        case 5: pass<5>(src, dst, twM, M, NS, inv_ns, lane); break;
-        case 6: pass<6>(src, dst, twM, M, NS, inv_ns, lane); break;
-        case 7: pass<7>(src, dst, twM, M, NS, inv_ns, lane); break;
-        case 8: pass<8>(src, dst, twM, M, NS, inv_ns, lane); break;
-        case 10: pass<10>(src, dst, twM, M, NS, inv_ns, lane); break;
-        case 12: pass<12>(src, dst, twM, M, NS, inv_ns, lane); break;
-        case 15: pass<15>(src, dst, twM, M, NS, inv_ns, lane); break;
-        default: pass<16>(src, dst, twM, M, NS, inv_ns, lane); break;
-      }
-      wave_sync();
-      float2* const t = const_cast<float2*>(src);
-      src = dst;
-      dst = t;
-      NS *= R;
-    }
+    const float2* src = transform(bufA, bufB, twM, ps, M, li, L);
     float* __restrict__ orow = p.frames + fi * (long long)N;
-    if (packed) {  // (x[2 n], x[2 n + 1]) = conj(y[n]) / (2 M): the sequence above was twice Z
-      for (int n = lane; n < M; n += 64) {
+    if (valid && packed) {  // (x[2 n], x[2 n + 1]) = conj(y[n]) / (2 M): the sequence above was twice Z
+      for (int n = li; n < M; n += L) {
         const float2 y = src[pos(n)];
         reinterpret_cast<float2*>(orow)[n] = {y.x * inv_n, -y.y * inv_n};
       }
-    } else {
-      for (int n = lane; n < M; n += 64) orow[n] = src[pos(n)].x * inv_n;
+    } else if (valid) {
+      for (int n = li; n < M; n += L) orow[n] = src[pos(n)].x * inv_n;
     }
-    wave_sync();  // the next frame overwrites the buffers
+    wave_sync();  // the next round overwrites the buffers
   }
 }
 
-static size_t lds_bytes(int M, int bins, int mode, int n_mels, int nnz, bool with_tables, int fpw) {
-  size_t b = sizeof(float2) * ((size_t)WAVES * 2 * buf_len(M) + M);
+static size_t lds_bytes(int M, int bins, int L, int mode, int n_mels, int nnz, bool with_tables, int fpw) {
+  const int gf = 64 / L;
+  size_t b = sizeof(float2) * ((size_t)WAVES * gf * 2 * buf_len(M) + M);
   if (mode != 0) {
-    b += sizeof(float) * (size_t)(WAVES * fpw) * (bins | 1);
+    b += sizeof(float) * (size_t)(WAVES * fpw * gf) * (bins | 1);
     if (with_tables) b += sizeof(float) * (size_t)nnz + 3 * sizeof(int) * (size_t)n_mels;
   }
   return b;
@@ -396,49 +395,64 @@ static size_t lds_bytes(int M, int bins, int mode, int n_mels, int nnz, bool wit
 
 }  // namespace wavefft
 
-// The butterflies of the plan for n_fft, or false: odd n_fft, a half length above 1024, a prime
-// factor above 7 or more than six passes.  Among the ordered factorisations into radices 2 .. 16
-// the cheapest by a count of wave instructions: a pass of radix R costs its 64-lane rounds
-// (butterflies / 64, rounded up - a radix above M / 64 leaves lanes idle) times the instructions
-// of one round (loads, twiddle products and stores per point plus the butterfly itself); the
-// first pass has no twiddles, so the largest radix goes first.
-bool forward_wave_plan(int n_fft, int* n_pass, int radix[6]) {
+// The butterflies of the plan for n_fft and the lanes a frame takes, or false: a (half) length
+// above 1024, a prime factor above 7 or more than six passes.  Among the ordered factorisations
+// into radices 2 .. 16 the cheapest per frame by a count of wave instructions: a pass of radix R
+// costs its rounds (butterflies / lanes per frame, rounded up) times the instructions of one
+// round (loads, twiddle products and stores per point plus the butterfly itself), and a frame
+// that needs only L of the 64 lanes shares the wave with 64 / L - 1 others.  The first pass has
+// no twiddles, so the largest radix goes first.
+bool forward_wave_plan(int n_fft, int* n_pass, int radix[6], int* lanes_per_frame) {
   using namespace wavefft;
   if (n_fft < 3 || (n_fft % 2 == 0 ? n_fft / 2 : n_fft) > MAXM) return false;
   static const int allowed[] = {16, 15, 12, 10, 8, 7, 6, 5, 4, 3, 2};
   static const int bfly[] = {170, 220, 110, 100, 60, 90, 45, 40, 16, 16, 4};  // instructions of Dft<R>
+  constexpr int NA = (int)(sizeof(allowed) / sizeof(allowed[0]));
   const int M = n_fft % 2 == 0 ? n_fft / 2 : n_fft;  // an odd n_fft is transformed unpacked
-  int best[MAXP], best_n = 0, cur[MAXP];
-  long best_cost = -1;
-  // depth-first over non-increasing radix sequences (the order of the passes does not change the cost)
-  struct Frame { int rem, depth, start; };
-  auto cost_of = [&](int n) {
-    long c = 0;
+  int best[MAXP], best_n = 0, best_l = 64, cur[MAXP];
+  double best_cost = -1.0;
+  // frames side by side in a wave each need their two buffers: at most 48 KB of them per workgroup,
+  // so that the power tile and a second workgroup still fit the CU
+  int lmin = 64;
+  while (lmin > 1 && (size_t)(64 / (lmin / 2)) * buf_len(M) <= 768) lmin /= 2;
+  auto lanes_of = [&](int n) {
+    int widest = 1;
+    for (int i = 0; i < n; ++i) widest = M / cur[i] > widest ? M / cur[i] : widest;
+    int l = lmin;
+    while (l < widest && l < 64) l *= 2;
+    return l;
+  };
+  auto cost_of = [&](int n, int l) {
+    double c = 0;
     for (int i = 0; i < n; ++i) {
       int a = 0;
       while (allowed[a] != cur[i]) ++a;
-      const int rounds = (M / cur[i] + 63) / 64;
-      c += (long)rounds * ((i == 0 ? 6 : 10) * cur[i] + bfly[a]) + 12;  // + per-pass set-up and sync
+      const int rounds = (M / cur[i] + l - 1) / l;
+      c += (double)rounds * ((i == 0 ? 6 : 10) * cur[i] + bfly[a]) + 12;  // + per-pass set-up and sync
     }
-    return c;
+    return c * l / 64.0;  // 64 / l frames share the wave's instructions
   };
-  // small search space (M <= 1024): plain recursion through an explicit stack
+  // depth-first over non-increasing radix sequences (the order of the passes does not change the cost)
   int idx[MAXP + 1] = {0};
   int rem[MAXP + 1];
   rem[0] = M;
   int d = 0;
   while (d >= 0) {
     if (rem[d] == 1) {
-      const long c = cost_of(d);
-      if (d >= 1 && (best_cost < 0 || c < best_cost)) {
-        best_cost = c;
-        best_n = d;
-        for (int i = 0; i < d; ++i) best[i] = cur[i];
+      if (d >= 1) {
+        const int l = lanes_of(d);
+        const double c = cost_of(d, l);
+        if (best_cost < 0 || c < best_cost) {
+          best_cost = c;
+          best_n = d;
+          best_l = l;
+          for (int i = 0; i < d; ++i) best[i] = cur[i];
+        }
       }
       --d;
       continue;
     }
-    if (d == MAXP || idx[d] >= (int)(sizeof(allowed) / sizeof(allowed[0]))) {
+    if (d == MAXP || idx[d] >= NA) {
       --d;
       continue;
     }
@@ -452,21 +466,27 @@ bool forward_wave_plan(int n_fft, int* n_pass, int radix[6]) {
   if (best_cost < 0) return false;
   for (int i = 0; i < best_n; ++i) radix[i] = best[i];
   *n_pass = best_n;
+  if (lanes_per_frame) *lanes_per_frame = best_l;
   return true;
 }
 
-// Frame-major rows leave through the FFT buffers (a tile's n_mels x frames values fit them for
-// every size the plan covers unless n_mels is very large).
+// Frame-major rows leave through the FFT buffers: a tile's n_mels x frames values must fit them
+// (true for every long transform; short ones, which put many frames into a tile, only with few bands).
 bool forward_wave_frame_major_ok(int n_fft, int n_mels) {
   using namespace wavefft;
-  return n_mels % 4 == 0 && sizeof(float) * (size_t)(WAVES * MAXFPW) * n_mels <=
-                                sizeof(float2) * (size_t)WAVES * 2 * buf_len(n_fft % 2 == 0 ? n_fft / 2 : n_fft);
+  int np = 0, radix[MAXP], l = 64;
+  if (!forward_wave_plan(n_fft, &np, radix, &l)) return false;
+  const int M = n_fft % 2 == 0 ? n_fft / 2 : n_fft;
+  const size_t gf = 64 / l;
+  return n_mels % 4 == 0 && sizeof(float) * (size_t)(WAVES * MAXFPW) * gf * n_mels <=
+                                sizeof(float2) * (size_t)WAVES * gf * 2 * buf_len(M);
 }
 
 int launch_forward_wave(const mia_plan* plan, const FwdParams& p0, int mode, hipStream_t s) {
   using namespace wavefft;
   Passes ps{};
-  if (!forward_wave_plan(plan->n_fft, &ps.n, ps.radix)) {
+  int L = 64;
+  if (!forward_wave_plan(plan->n_fft, &ps.n, ps.radix, &L)) {
     set_error("n_fft=%d is not served by the per-wave transform", plan->n_fft);
     return MIA_ERR_UNSUPPORTED;
   }
@@ -482,11 +502,11 @@ int launch_forward_wave(const mia_plan* plan, const FwdParams& p0, int mode, hip
   // Frames per wave and tile: two (a tile of eight frames: 32-byte runs of a mel row), or one
   // where that lets a second workgroup onto the CU (long transforms with a power tile).
   int fpw = MAXFPW;
-  if (kmode != 0 && lds_bytes(M, bins, kmode, p.n_mels, p.nnz, false, 2) > 80 * 1024 &&
-      lds_bytes(M, bins, kmode, p.n_mels, p.nnz, false, 1) <= 80 * 1024) {
+  if (kmode != 0 && lds_bytes(M, bins, L, kmode, p.n_mels, p.nnz, false, 2) > 80 * 1024 &&
+      lds_bytes(M, bins, L, kmode, p.n_mels, p.nnz, false, 1) <= 80 * 1024) {
     fpw = 1;
   }
-  const int FT = WAVES * fpw;
+  const int FT = WAVES * fpw * (64 / L);
   p.tiles = (int)((p.F + FT - 1) / FT);
   const long long total = p.B * p.tiles;
   if (total <= 0) return MIA_OK;
@@ -494,10 +514,10 @@ int launch_forward_wave(const mia_plan* plan, const FwdParams& p0, int mode, hip
     set_error("%lld tiles do not fit one launch (split the batch)", total);
     return MIA_ERR_UNSUPPORTED;
   }
-  size_t lds = lds_bytes(M, bins, kmode, p.n_mels, p.nnz, false, fpw);
+  size_t lds = lds_bytes(M, bins, L, kmode, p.n_mels, p.nnz, false, fpw);
   p.lds_tables = 0;
-  if (kmode != 0 && lds_bytes(M, bins, kmode, p.n_mels, p.nnz, true, fpw) <= 80 * 1024) {
-    lds = lds_bytes(M, bins, kmode, p.n_mels, p.nnz, true, fpw);  // band tables ride along while two workgroups fit a CU
+  if (kmode != 0 && lds_bytes(M, bins, L, kmode, p.n_mels, p.nnz, true, fpw) <= 80 * 1024) {
+    lds = lds_bytes(M, bins, L, kmode, p.n_mels, p.nnz, true, fpw);  // band tables ride along while two workgroups fit a CU
     p.lds_tables = 1;
   }
   if (lds > 160 * 1024) {
@@ -523,7 +543,7 @@ int launch_forward_wave(const mia_plan* plan, const FwdParams& p0, int mode, hip
   }
   p.tiles_per_wg = (int)per_wg;
   grid = (total + per_wg - 1) / per_wg;
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WG), lds, s, p, ps, M, fpw, packed);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WG), lds, s, p, ps, M, fpw, packed, L);
   MIA_CHECK_HIP(hipGetLastError());
   return MIA_OK;
 }
@@ -531,15 +551,17 @@ int launch_forward_wave(const mia_plan* plan, const FwdParams& p0, int mode, hip
 int launch_inverse_wave(const mia_plan* plan, const InvParams& p, hipStream_t s) {
   using namespace wavefft;
   Passes ps{};
-  if (!forward_wave_plan(plan->n_fft, &ps.n, ps.radix)) {
+  int L = 64;
+  if (!forward_wave_plan(plan->n_fft, &ps.n, ps.radix, &L)) {
     set_error("n_fft=%d is not served by the per-wave transform", plan->n_fft);
     return MIA_ERR_UNSUPPORTED;
   }
   const int packed = plan->n_fft % 2 == 0 ? 1 : 0;
   const int M = packed ? plan->n_fft / 2 : plan->n_fft;
+  const int per_round = WAVES * (64 / L);  // frames a workgroup takes at a time
   const long long total = p.B * p.F;
   if (total <= 0) return MIA_OK;
-  const size_t lds = sizeof(float2) * ((size_t)WAVES * 2 * buf_len(M) + M);
+  const size_t lds = sizeof(float2) * ((size_t)per_round * 2 * buf_len(M) + M);
   auto kern = inv_wave_kernel;
   if (lds > 64 * 1024) {
     MIA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -551,11 +573,11 @@ int launch_inverse_wave(const mia_plan* plan, const InvParams& p, hipStream_t s)
     per_cu = 1;
   }
   long long grid = (long long)(plan->cus > 0 ? plan->cus : 256) * per_cu;
-  const long long groups = (total + WAVES - 1) / WAVES;  // a workgroup takes four frames at a time
+  const long long groups = (total + per_round - 1) / per_round;
   if (grid > groups) grid = groups;
-  const long long per_wg = ((groups + grid - 1) / grid) * WAVES;
+  const long long per_wg = ((groups + grid - 1) / grid) * per_round;
   grid = (total + per_wg - 1) / per_wg;
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WG), lds, s, p, ps, M, packed, per_wg);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WG), lds, s, p, ps, M, packed, L, per_wg);
   MIA_CHECK_HIP(hipGetLastError());
   return MIA_OK;
 }

@@ -368,7 +368,8 @@ def test_wave_private_kernel_option(gpu, hop, n_mels, pad_mode, served):
 
 
 @pytest.mark.parametrize("n_fft,hop,n_mels,sr", [(480, 160, 80, 16000), (960, 480, 64, 48000), (882, 441, 40, 44100),
-                                                (1200, 300, 128, 48000), (320, 80, 24, 16000)])
+                                                (1200, 300, 128, 48000), (320, 80, 24, 16000), (64, 16, 20, 16000),
+                                                (128, 32, 40, 16000)])
 def test_mel_chain_on_the_per_wave_transform(gpu, n_fft, hop, n_mels, sr):
     """n_fft without a compiled plan but with a 7-smooth half length (20 / 30 ms windows at 16,
     44.1 and 48 kHz): mel power, magnitude mel, dB with a per-clip top_db floor, frame-major rows and
@@ -399,7 +400,6 @@ def test_mel_chain_on_the_per_wave_transform(gpu, n_fft, hop, n_mels, sr):
     assert np.abs(a.cpu().numpy() - want).max() <= 2e-3
     b = _mel_raw(*args, frames_first=True, **kw)
     assert b.shape == (3, a.shape[2], n_mels) and torch.equal(a.transpose(1, 2), b)
-    assert b.is_contiguous() == (n_mels % 4 == 0)
     c = mfcc(y, sr=sr, n_mfcc=13, n_fft=n_fft, hop_length=hop, n_mels=n_mels, per_clip=True)
     wantc = np.stack([o.mfcc(x[i], sr=sr, n_mfcc=13, n_fft=n_fft, hop_length=hop, n_mels=n_mels) for i in range(3)])
     np.testing.assert_allclose(c.cpu().numpy(), wantc, rtol=1e-4, atol=5e-3)
