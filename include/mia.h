@@ -224,7 +224,8 @@ int mia_frame_signal(const float* x, int64_t B, int64_t T, int frame_length, int
                      float* out, void* stream);
 /* primitives/convert.py:14-57 on an existing array: x viewed as (B, n) —
  * out = coef*log10(max(x,amin)/max(ref,amin)), clamped to (max - top_db) per row
- * (per_clip) or over everything; top_db < 0: no clamp.  workspace: >= 4*(B+1) bytes. */
+ * (per_clip) or over everything; top_db < 0: no clamp.  workspace: >= 8*(B+1) bytes (row maxima and
+ * minima: rows that do not reach below their floor are not touched a second time). */
 int mia_to_db(const float* x, int64_t B, int64_t n, float ref, float amin, float coef,
               float top_db, int per_clip, float* out, void* workspace, void* stream);
 /* _ext.dct (bindings.cpp:342-370, csrc/primitives/dct.cpp:103-159) along the

@@ -83,23 +83,45 @@ __global__ __launch_bounds__(256) void frame_kernel(const float* __restrict__ x,
 __global__ __launch_bounds__(256) void to_db_kernel(const float* __restrict__ x, long long n,
                                                      float amin, float inv_ref, float coef,
                                                      float* __restrict__ out,
-                                                     int* __restrict__ keys) {
+                                                     int* __restrict__ max_keys, int* __restrict__ min_keys,
+                                                     int vec4) {
   const long long b = blockIdx.y;
   int kmax = kKeyMinusInf;  // integer keys: a NaN value wins the maximum, as in the reference
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-       i += (long long)gridDim.x * blockDim.x) {
-    const float xv = x[b * n + i];
+  float vmin = INFINITY;
+  auto one = [&](float xv) {
     const float v = coef * log10f((xv < amin ? amin : xv) * inv_ref);  // a NaN stays a NaN
-    out[b * n + i] = v;
     kmax = max(kmax, float_to_key_nan(v));
+    vmin = fminf(vmin, v);
+    return v;
+  };
+  const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  if (vec4) {  // rows of whole, 16-byte-aligned quads
+    const float4* __restrict__ x4 = reinterpret_cast<const float4*>(x + b * n);
+    float4* __restrict__ o4 = reinterpret_cast<float4*>(out + b * n);
+    for (long long i = tid; i < n / 4; i += stride) {
+      const float4 q = x4[i];
+      o4[i] = {one(q.x), one(q.y), one(q.z), one(q.w)};
+    }
+  } else {
+    for (long long i = tid; i < n; i += stride) out[b * n + i] = one(x[b * n + i]);
   }
+  if (max_keys == nullptr) return;
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) kmax = max(kmax, __shfl_xor(kmax, off));
+  for (int off = 32; off > 0; off >>= 1) {
+    kmax = max(kmax, __shfl_xor(kmax, off));
+    vmin = fminf(vmin, __shfl_xor(vmin, off));
+  }
   __shared__ int red[4];
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = kmax;
+  __shared__ float redm[4];
+  if ((threadIdx.x & 63) == 0) {
+    red[threadIdx.x >> 6] = kmax;
+    redm[threadIdx.x >> 6] = vmin;
+  }
   __syncthreads();
-  if (threadIdx.x == 0 && keys != nullptr) {
-    atomicMax(keys + b, max(max(red[0], red[1]), max(red[2], red[3])));
+  if (threadIdx.x == 0) {
+    atomicMax(max_keys + b, max(max(red[0], red[1]), max(red[2], red[3])));
+    atomicMin(min_keys + b, float_to_key(fminf(fminf(redm[0], redm[1]), fminf(redm[2], redm[3]))));
   }
 }
 
@@ -125,17 +147,6 @@ __device__ __forceinline__ float floor_from_key(int key, int epi, float top) {
   const float gmax = key_to_float(key);
   if (epi == MIA_EPI_WHISPER) return ((gmax - top) + 4.0f) * 0.25f;
   return gmax - top;
-}
-
-__global__ __launch_bounds__(256) void floor_rows_kernel(float* __restrict__ x, long long n,
-                                                          const int* __restrict__ keys,
-                                                          long long key_stride, float top) {
-  const long long b = blockIdx.y;
-  const float thr = floor_from_key(keys[b * key_stride], MIA_EPI_DB, top);
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-       i += (long long)gridDim.x * blockDim.x) {
-    x[b * n + i] = floor_nan(x[b * n + i], thr);
-  }
 }
 
 // Both key arrays of a mel call in one launch (two hipMemsetD32Async cost four fill
@@ -214,31 +225,32 @@ __global__ __launch_bounds__(256) void floor_clips_kernel(float* __restrict__ x,
   }
 }
 
+int launch_floor_clips(float* x, long long B, long long n, int* max_keys, const int* min_keys,
+                       int epi, float top, int per_clip, hipStream_t s);
+
+// Stand-alone dB conversion: one pass that writes the values and takes every row's maximum and
+// minimum, then the floor pass of the fused kernels, which touches only rows that reach below
+// their floor (most inputs span less than top_db: the values are then read once and written once).
+// keys: 2 (B + 1) ints of workspace.
 int launch_to_db(const float* x, long long B, long long n, float ref, float amin, float coef,
                  float top_db, int per_clip, float* out, int* keys, hipStream_t s) {
   if (B <= 0 || n <= 0) return MIA_OK;
   const bool clamp = top_db >= 0.0f;
+  int* const min_keys = keys ? keys + (B + 1) : nullptr;
   if (clamp) {
-    MIA_CHECK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(keys), kKeyMinusInf,
-                                    (size_t)B + 1, s));
+    const int rc = launch_init_keys(keys, min_keys, B + 1, s);
+    if (rc != MIA_OK) return rc;
   }
   const float refv = fmaxf(ref, amin);
-  long long bx = (n + 256 * 8 - 1) / (256 * 8);
+  const int vec4 = n % 4 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+  long long bx = (n + 256 * 16 - 1) / (256 * 16);
   if (bx > 4096) bx = 4096;
   if (bx < 1) bx = 1;
   dim3 grid((unsigned)bx, (unsigned)B);
   hipLaunchKernelGGL(to_db_kernel, grid, dim3(256), 0, s, x, n, amin, 1.0f / refv, coef, out,
-                     clamp ? keys : nullptr);
+                     clamp ? keys : nullptr, min_keys, vec4);
   MIA_CHECK_HIP(hipGetLastError());
-  if (clamp) {
-    if (!per_clip) {
-      hipLaunchKernelGGL(reduce_keys_kernel, dim3(1), dim3(256), 0, s, keys, B);
-      MIA_CHECK_HIP(hipGetLastError());
-    }
-    hipLaunchKernelGGL(floor_rows_kernel, grid, dim3(256), 0, s, out, n,
-                       per_clip ? keys : keys + B, (long long)(per_clip ? 1 : 0), top_db);
-    MIA_CHECK_HIP(hipGetLastError());
-  }
+  if (clamp) return launch_floor_clips(out, B, n, keys, min_keys, MIA_EPI_DB, top_db, per_clip, s);
   return MIA_OK;
 }
 

@@ -36,7 +36,7 @@ def _to_db(S, ref, coefficient: float, amin: float, top_db, per_clip: bool) -> t
     else:
         B, n = 1, S.numel()
     out = torch.empty_like(S)
-    ws = torch.empty((4 * (B + 1),), dtype=torch.uint8, device=S.device)
+    ws = torch.empty((8 * (B + 1),), dtype=torch.uint8, device=S.device)
     with torch.cuda.device(S.device):
         _lib.check(_lib.lib().mia_to_db(
             S.data_ptr(), B, n, ref_value, float(amin), float(coefficient),

@@ -403,3 +403,26 @@ def test_mel_chain_on_the_per_wave_transform(gpu, n_fft, hop, n_mels, sr):
     c = mfcc(y, sr=sr, n_mfcc=13, n_fft=n_fft, hop_length=hop, n_mels=n_mels, per_clip=True)
     wantc = np.stack([o.mfcc(x[i], sr=sr, n_mfcc=13, n_fft=n_fft, hop_length=hop, n_mels=n_mels) for i in range(3)])
     np.testing.assert_allclose(c.cpu().numpy(), wantc, rtol=1e-4, atol=5e-3)
+
+
+def test_power_to_db_shapes_and_floors(gpu):
+    """The stand-alone conversion on arrays whose rows do / do not reach below the floor, with the
+    maximum per clip and over everything, on odd row lengths (scalar path) and whole quads."""
+    from mlx_audio_amd.primitives import amplitude_to_db, power_to_db
+
+    rng = np.random.default_rng(3)
+    for shape in ((5, 64, 101), (3, 128, 400), (1, 7), (4, 33, 1)):
+        S = (rng.random(shape) + 1e-3).astype(np.float32)
+        S[0].flat[::7] *= 1e-12     # this row reaches far below the floor
+        if shape[0] > 2:
+            S[2] *= 1e3             # ... and this one holds the global maximum
+        x = torch.from_numpy(S).to(gpu)
+        for top_db in (80.0, 20.0, None):
+            got = power_to_db(x, top_db=top_db).cpu().numpy()
+            np.testing.assert_allclose(got, o.power_to_db(S, top_db=top_db), rtol=0, atol=2e-4)
+            if S.ndim >= 2:
+                got = power_to_db(x, top_db=top_db, per_clip=True).cpu().numpy()
+                want = np.stack([o.power_to_db(S[i], top_db=top_db) for i in range(S.shape[0])])
+                np.testing.assert_allclose(got, want, rtol=0, atol=2e-4)
+        got = amplitude_to_db(x, ref=2.0, top_db=30.0).cpu().numpy()
+        np.testing.assert_allclose(got, o.amplitude_to_db(S, ref=2.0, top_db=30.0), rtol=0, atol=2e-4)
