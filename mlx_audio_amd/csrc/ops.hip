@@ -343,94 +343,7 @@ __global__ __launch_bounds__(256) void dct2_kernel(const float* __restrict__ x, 
 //   D(mb)    : lane l holds rows 16 mb + 4 (l / 16) + r, r = 0..3, of position 16 w + l % 16
 typedef float dct_floatx4 __attribute__((ext_vector_type(4)));
 constexpr int kDctMaxMB = 3, kDctKS = 32;  // up to 48 rows (MB blocks of 16), 128 taps
-template <int kDctMB>
-__global__ __launch_bounds__(256) void dct2_mfma_kernel(const float* __restrict__ x, int n_in,
-                                                         long long inner,
-                                                         const float* __restrict__ basis, int n_out,
-                                                         float* __restrict__ out,
-                                                         const int* __restrict__ keys,
-                                                         long long key_stride, float top,
-                                                         long long tiles_per_row, long long total,
-                                                         int tiles_per_wg) {
-  __shared__ float slab[128 * 64];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int row = lane & 15, kq = lane >> 4;
-  float a[kDctMB][kDctKS];
-#pragma unroll
-  for (int mb = 0; mb < kDctMB; ++mb) {
-#pragma unroll
-    for (int ks = 0; ks < kDctKS; ++ks) {
-      const int m = 16 * mb + row, k = 4 * ks + kq;
-      a[mb][ks] = (m < n_out && k < n_in) ? basis[(long long)m * n_in + k] : 0.0f;
-    }
-  }
-  // Tiles are dealt round-robin: at any moment the resident workgroups read neighbouring
-  // 256-byte pieces of the same rows (rows are `inner` floats apart, pieces of one tile lie in
-  // n_in different rows), so that a row's lines and DRAM pages are used up together instead of
-  // every workgroup streaming through its own n_in rows.
-  const long long first = blockIdx.x, last = total, step = gridDim.x;
-  (void)tiles_per_wg;
-  // The tile's inputs are fetched one tile ahead into registers (they fly during the
-  // MFMAs of the current tile) and reach the slab, floored, after its last reader.
-  float nx[32];
-  int nkey = 0;  // the clip's maximum key travels with the prefetch
-  auto fetch = [&](long long idx_n) {
-    const long long o = idx_n / tiles_per_row;
-    if (keys && idx_n < last) nkey = keys[o * key_stride];
-    const long long i0 = (idx_n - o * tiles_per_row) * 64;
-    const bool ok = idx_n < last && i0 + lane < inner;
-#pragma unroll
-    for (int j = 0; j < 32; ++j) {
-      const int n = wave + 4 * j;
-      nx[j] = (ok && n < n_in) ? x[(o * n_in + n) * inner + i0 + lane] : 0.0f;
-    }
-  };
-  fetch(first);
-  for (long long idx = first; idx < last; idx += step) {
-    const long long o = idx / tiles_per_row;
-    const long long i0 = (idx - o * tiles_per_row) * 64;
-    const float thr = keys ? floor_from_key(nkey, MIA_EPI_DB, top) : -INFINITY;
-#pragma unroll
-    for (int j = 0; j < 32; ++j) {
-      const int n = wave + 4 * j;
-      slab[n * 64 + lane] = n < n_in ? floor_nan(nx[j], thr) : 0.0f;
-    }
-    __syncthreads();
-    fetch(idx + step);
-    float bv[kDctKS];
-#pragma unroll
-    for (int ks = 0; ks < kDctKS; ++ks) bv[ks] = slab[(4 * ks + kq) * 64 + 16 * wave + row];
-    dct_floatx4 acc[kDctMB];
-#pragma unroll
-    for (int mb = 0; mb < kDctMB; ++mb) acc[mb] = dct_floatx4{0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-    for (int ks = 0; ks < kDctKS; ++ks) {
-#pragma unroll
-      for (int mb = 0; mb < kDctMB; ++mb) {
-        acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb][ks], bv[ks], acc[mb], 0, 0, 0);
-      }
-    }
-    // The prefetched inputs are waited for HERE, behind the MFMAs and before this tile's
-    // stores: waited for at the top of the loop, the in-order counter would also wait for
-    // the acknowledgements of these stores.
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-    const long long pos = i0 + 16 * wave + row;
-    if (pos < inner) {
-#pragma unroll
-      for (int mb = 0; mb < kDctMB; ++mb) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int m = 16 * mb + 4 * kq + r;
-          if (m < n_out) out[(o * n_out + m) * inner + pos] = acc[mb][r];
-        }
-      }
-    }
-    __syncthreads();  // the next tile overwrites the slab
-  }
-}
-
-// The same kernel for input stored position-major, x[o, i, n] (the layout the generic mel kernel
+// The kernel for input stored position-major, x[o, i, n] (the layout the generic mel kernel
 // writes for the MFCC path: a tile of 64 positions is one contiguous run of 64 * n_in floats).
 // Needs n_in % 4 == 0.  The slab is [position][n_in + 4]: whole float4 stores when staging, and
 // the B operand reads (16 positions x 4 taps per wave instruction) are 2-way at most.
@@ -527,7 +440,7 @@ __global__ __launch_bounds__(256) void dct2_mfma_fm_kernel(const float* __restri
 // Workgroups of a matrix-core DCT kernel that one CU holds (by its registers and its LDS slab),
 // asked once per instantiation and device.
 static int dct_resident_per_cu(const void* kern, int which) {
-  static int cached[2 * kDctMaxMB][16] = {{0}};
+  static int cached[kDctMaxMB][16] = {{0}};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
   if (cached[which][dev] == 0) {
@@ -538,6 +451,72 @@ static int dct_resident_per_cu(const void* kern, int which) {
     cached[which][dev] = per_cu;
   }
   return cached[which][dev];
+}
+
+// Row-major input without a slab: a wave owns 64 positions of one `o`, lane = position.  Every
+// row piece is one coalesced 256-byte load, sixteen of them in flight per wave; the basis values
+// are the same in every lane and come through the scalar cache (eight consecutive taps of one
+// coefficient per s_load_dwordx8); NK accumulators per lane.  Arithmetic and its order equal the
+// matrix-core kernels' (fma chain over ascending taps).  Few registers, no LDS, no barrier: five
+// to eight waves per SIMD keep 100+ KB of loads in flight per CU, which the slab kernels with
+// their 2 - 3 workgroups per CU cannot.
+template <int NK>
+__global__ __launch_bounds__(256) void dct2_stream_kernel(const float* __restrict__ x, int n_in, long long inner,
+                                                           const float* __restrict__ basis, int n_out,
+                                                           float* __restrict__ out, const int* __restrict__ keys,
+                                                           long long key_stride, float top, long long tiles_per_row,
+                                                           long long total) {
+  constexpr int CH = 16;
+  const int lane = threadIdx.x & 63;
+  const long long gw = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const long long step = (long long)gridDim.x * 4;
+  for (long long tile = gw; tile < total; tile += step) {
+    const long long o = tile / tiles_per_row;
+    const long long pos = (tile - o * tiles_per_row) * 64 + lane;
+    const bool ok = pos < inner;
+    const float thr = keys ? floor_from_key(keys[o * key_stride], MIA_EPI_DB, top) : -INFINITY;
+    const float* __restrict__ xp = x + (o * n_in) * inner + (ok ? pos : 0);
+    float acc[NK];
+#pragma unroll
+    for (int k = 0; k < NK; ++k) acc[k] = 0.0f;
+    float cur[CH], nxt[CH];
+    auto fetch = [&](float (&dst)[CH], int n0) {
+#pragma unroll
+      for (int j = 0; j < CH; ++j) dst[j] = (ok && n0 + j < n_in) ? xp[(long long)(n0 + j) * inner] : 0.0f;
+    };
+    fetch(cur, 0);
+    for (int n0 = 0; n0 < n_in; n0 += CH) {
+      if (n0 + CH < n_in) fetch(nxt, n0 + CH);
+      float v[CH];
+#pragma unroll
+      for (int j = 0; j < CH; ++j) v[j] = floor_nan(cur[j], thr);
+      if (n0 + CH <= n_in) {
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+          if (k < n_out) {
+            const float* __restrict__ brow = basis + (long long)k * n_in + n0;
+#pragma unroll
+            for (int j = 0; j < CH; ++j) acc[k] = fmaf(brow[j], v[j], acc[k]);
+          }
+        }
+      } else {  // the last, partial chunk
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+          if (k < n_out) {
+            for (int j = 0; n0 + j < n_in; ++j) acc[k] = fmaf(basis[(long long)k * n_in + n0 + j], v[j], acc[k]);
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < CH; ++j) cur[j] = nxt[j];
+    }
+    if (ok) {
+#pragma unroll
+      for (int k = 0; k < NK; ++k) {
+        if (k < n_out) out[(o * n_out + k) * inner + pos] = acc[k];
+      }
+    }
+  }
 }
 
 bool dct2_frame_major_ok(int n_in, int n_out) {
@@ -580,25 +559,23 @@ int launch_dct2(const float* x, long long outer, int n_in, long long inner, cons
                 int n_out, float* out, const int* keys, long long key_stride, float top,
                 hipStream_t s) {
   if (outer <= 0 || inner <= 0 || n_out <= 0) return MIA_OK;
-  if (n_in <= 4 * kDctKS && n_out <= 16 * kDctMaxMB && n_in >= 32) {
+  if (n_out <= 48) {
     const long long tiles_per_row = (inner + 63) / 64;
     const long long total = outer * tiles_per_row;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) {
       (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     }
-    const int mb = n_out <= 16 ? 1 : (n_out <= 32 ? 2 : 3);
-    auto kern = mb == 1 ? dct2_mfma_kernel<1> : (mb == 2 ? dct2_mfma_kernel<2> : dct2_mfma_kernel<3>);
-    long long grid = (long long)cus * dct_resident_per_cu(reinterpret_cast<const void*>(kern), kDctMaxMB + mb - 1);
-    if (grid > total) grid = total;
-    const long long per_wg = (total + grid - 1) / grid;
-    if (per_wg <= 0x7fffffffLL) {
-      grid = (total + per_wg - 1) / per_wg;
-      hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), 0, s, x, n_in, inner,
-                         basis, n_out, out, keys, key_stride, top, tiles_per_row, total, (int)per_wg);
-      MIA_CHECK_HIP(hipGetLastError());
-      return MIA_OK;
-    }
+    auto kern = n_out <= 16 ? dct2_stream_kernel<16>
+                            : (n_out <= 24 ? dct2_stream_kernel<24>
+                                           : (n_out <= 32 ? dct2_stream_kernel<32>
+                                                          : (n_out <= 40 ? dct2_stream_kernel<40> : dct2_stream_kernel<48>)));
+    long long grid = (long long)cus * 8;  // 32 waves per CU at most; a wave walks tiles grid-strided
+    if (grid * 4 > total) grid = (total + 3) / 4;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), 0, s, x, n_in, inner, basis, n_out, out, keys,
+                       key_stride, top, tiles_per_row, total);
+    MIA_CHECK_HIP(hipGetLastError());
+    return MIA_OK;
   }
   const size_t lds = sizeof(float) * 64 * (size_t)n_in;
   if (lds > 160 * 1024) {
