@@ -4,8 +4,8 @@
 // Statistics: one thread per frame; consecutive lanes hold consecutive frames, so every
 // load of bin k is one coalesced row segment and each thread walks the bins in order with
 // its own float32 accumulators (the summation order of a sequential reduction over the
-// frequency axis).  The spectrogram is read once (twice for the roll-off frequency: total,
-// then the running sum).  Zero crossings: one wave per frame, lanes striding the samples.
+// frequency axis).  The spectrogram is read once (for the roll-off frequency once for the total
+// and then the few rows around the crossing; twice when all four statistics come together).  Zero crossings: one wave per frame, lanes striding the samples.
 #include "mia_internal.h"
 
 namespace mia {
@@ -21,6 +21,7 @@ __device__ __forceinline__ float pow_in(float v, int power_mode, float power) {
 // mode 0: centroid  sum(f S) / (sum S + eps)
 // mode 1: bandwidth (sum(S |f - c|^p) [/ (sum S + eps)])^(1/p), c = aux[row, frame]
 // mode 2: roll-off  f[first k with cumsum_k >= fraction * total], last bin if none
+//         (spectral_rolloff_kernel below; here only as part of mode 4)
 // mode 3: flatness  exp(mean log max(S^power, amin)) / (mean max(S^power, amin) + eps)
 __global__ __launch_bounds__(256) void spectral_stat_kernel(
     const float* __restrict__ S, long long rows, int bins, long long F,
@@ -53,23 +54,6 @@ __global__ __launch_bounds__(256) void spectral_stat_kernel(
     }
     if (norm) ws = ws / (ts + kDivEps);
     result = p == 2.0f ? sqrtf(ws) : (p == 1.0f ? ws : powf(ws, 1.0f / p));
-  } else if (mode == 2) {
-    float total = 0.0f;
-#pragma unroll 8
-    for (int k = 0; k < bins; ++k) total += col[(long long)k * F];
-    const float thr = fraction * total;
-    float cs = 0.0f;
-    int hit = bins - 1;
-    bool open = true;
-#pragma unroll 8
-    for (int k = 0; k < bins; ++k) {
-      cs += col[(long long)k * F];
-      if (open && cs >= thr) {
-        hit = k;
-        open = false;
-      }
-    }
-    result = freq[hit];
   } else if (mode == 4) {
     // all four in two passes: sums first, then the spread around the centroid and the
     // roll-off point; out is (rows, 4, frames) = centroid, bandwidth, roll-off, flatness, each
@@ -121,6 +105,90 @@ __global__ __launch_bounds__(256) void spectral_stat_kernel(
     result = expf(ls / (float)bins) / (as / (float)bins + kDivEps);
   }
   out[g] = result;
+}
+
+// Roll-off with one and a bit passes.  The first pass sums the column and leaves the running sum
+// at the end of every block of `cb` bins in LDS (kRollBlocks checkpoints per thread, laid out
+// [block][thread]).  With no negative (or NaN) value in the wave's columns the running sum never
+// decreases, so the first bin whose running sum reaches the threshold lies in the first block whose
+// checkpoint does; the second pass restarts from the checkpoint in front of that block and adds the
+// block's bins in the same order - the sums it compares are bit for bit those of the full scan.
+// The wave re-reads the rows from its lanes' lowest block to their highest one (whole coalesced
+// rows; neighbouring frames cross at neighbouring bins).  A wave that saw a negative value or a NaN
+// scans everything again from the first bin.
+constexpr int kRollBlocks = 32;
+__global__ __launch_bounds__(256) void spectral_rolloff_kernel(
+    const float* __restrict__ S, long long rows, int bins, long long F, const float* __restrict__ freq,
+    float fraction, float* __restrict__ out) {
+  __shared__ float ck[kRollBlocks][256];
+  const int tid = threadIdx.x;
+  const long long g0 = (long long)blockIdx.x * blockDim.x + tid;
+  const bool live = g0 < rows * F;
+  const long long g = live ? g0 : rows * F - 1;  // idle lanes shadow the last frame, store nothing
+  const long long row = g / F, f = g - row * F;
+  const float* __restrict__ col = S + row * bins * F + f;
+  // blocks of whole chunks of 8 bins: the loops below fetch a chunk's 8 rows, then add them in order
+  const int cb = 8 * ((bins + 8 * kRollBlocks - 1) / (8 * kRollBlocks));
+  const int nb = (bins + cb - 1) / cb;
+  float total = 0.0f;
+  bool mono = true;
+  for (int b = 0; b < nb; ++b) {
+    const int k1 = min((b + 1) * cb, bins);
+    int k = b * cb;
+    for (; k + 8 <= k1; k += 8) {
+      float v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = col[(long long)(k + i) * F];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        total += v[i];
+        mono = mono && v[i] >= 0.0f;
+      }
+    }
+    for (; k < k1; ++k) {
+      const float v = col[(long long)k * F];
+      total += v;
+      mono = mono && v >= 0.0f;
+    }
+    ck[b][tid] = total;
+  }
+  const float thr = fraction * total;
+  int hit = bins - 1;
+  float cs = 0.0f;
+  bool open = true;
+  int lo = 0, hi = bins, my_lo = 0, my_hi = bins;
+  if (__all(mono)) {
+    int j = nb;
+    for (int b = nb - 1; b >= 0; --b) j = ck[b][tid] >= thr ? b : j;
+    // a lane without a crossing (j == nb) takes no part in the range and keeps the last bin
+    my_lo = lo = j < nb ? j * cb : bins;
+    my_hi = hi = j < nb ? min((j + 1) * cb, bins) : 0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      lo = min(lo, __shfl_xor(lo, off));
+      hi = max(hi, __shfl_xor(hi, off));
+    }
+    if (j > 0 && j < nb) cs = ck[j - 1][tid];
+  }
+  auto step = [&](int k, float v) {
+    if (k >= my_lo && k < my_hi) {
+      cs += v;
+      if (open && cs >= thr) {
+        hit = k;
+        open = false;
+      }
+    }
+  };
+  int k = lo;
+  for (; k + 8 <= hi; k += 8) {
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = col[(long long)(k + i) * F];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) step(k + i, v[i]);
+  }
+  for (; k < hi; ++k) step(k, col[(long long)k * F]);
+  if (live) out[g0] = freq[hit];
 }
 
 // Spectral contrast: per frame and band, the mean of the nq smallest (valley) and of the nq
@@ -237,6 +305,13 @@ int mia_spectral_stat(const float* S, int64_t rows, int bins, int64_t frames, co
     return MIA_ERR_UNSUPPORTED;
   }
   const int power_mode = power == 1.0f ? 0 : (power == 2.0f ? 1 : 2);
+  if (mode == MIA_STAT_ROLLOFF) {
+    hipLaunchKernelGGL(spectral_rolloff_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, S, (long long)rows, bins, (long long)frames, freq, fraction,
+                       out);
+    MIA_CHECK_HIP(hipGetLastError());
+    return MIA_OK;
+  }
   hipLaunchKernelGGL(spectral_stat_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                      (hipStream_t)stream, S, (long long)rows, bins, (long long)frames, freq, aux,
                      mode, p, norm, fraction, amin, power_mode, power, out);

@@ -188,6 +188,41 @@ def test_all_four_in_one_launch_equal_the_single_statistics(gpu):
             assert torch.equal(allf[..., 3:4, :], spectral_flatness(S=S * S))
 
 
+def test_rolloff_checkpoint_scan_equals_the_full_scan(gpu):
+    """The roll-off kernel restarts its second pass from a checkpoint of the running sum; the
+    all-statistics kernel scans every bin again.  Same bits, whatever the columns look like:
+    peaks at scattered bins (every lane crosses in another block), empty columns, infinities,
+    and - through the fallback of a wave that meets them - negative values and NaNs."""
+    from mlx_audio_amd.primitives import spectrogram_statistics
+
+    rng = np.random.default_rng(77)
+    for bins, frames in ((1025, 300), (2049, 70), (129, 1000), (33, 64), (7, 500), (4097, 65)):
+        S = (rng.standard_normal((2, bins, frames)).astype(np.float32) ** 2) * 1e-3
+        peak = rng.integers(0, bins, size=(2, frames))
+        for r in range(2):
+            S[r, peak[r], np.arange(frames)] += 50.0
+        S[0, :, 3] = 0.0
+        S[1, bins // 2, 5] = np.inf
+        cases = {"plain": S}
+        neg = S.copy()
+        neg[0, 1:bins:3, 10:20] *= -1.0
+        cases["negative"] = neg
+        nan = S.copy()
+        nan[1, bins - 1, 7] = np.nan
+        cases["nan"] = nan
+        n_fft = 2 * (bins - 1)
+        for name, arr in cases.items():
+            Sd = _dev(arr, gpu)
+            for roll in (0.85, 0.3, 0.0, 1.0):
+                r = spectral_rolloff(S=Sd, sr=22050, n_fft=n_fft, roll_percent=roll)
+                allf = spectrogram_statistics(Sd, sr=22050, n_fft=n_fft, roll_percent=roll, power=2.0)
+                assert torch.equal(allf[..., 2:3, :], r), (bins, name, roll)
+                want = orc.spectral_rolloff(S=arr, sr=22050, n_fft=n_fft, roll_percent=roll)
+                got = r.cpu().numpy()
+                assert np.abs(got - want).max() <= 22050 / n_fft * 1.001, (bins, name, roll)
+                assert (got != want).mean() <= 0.02, (bins, name, roll)
+
+
 def test_short_signals_and_c_abi_checks(gpu):
     with pytest.raises(ValueError, match="must be >= frame_length"):
         zero_crossing_rate(_dev(np.zeros(10, np.float32), gpu), frame_length=64, center=False)
