@@ -18,6 +18,20 @@ __device__ __forceinline__ float pow_in(float v, int power_mode, float power) {
   return powf(v, power);
 }
 
+// Walks a column in order, eight rows fetched ahead of the arithmetic that consumes them.
+template <typename Fn>
+__device__ __forceinline__ void for_bins(const float* __restrict__ col, int bins, long long F, Fn&& fn) {
+  int k = 0;
+  for (; k + 8 <= bins; k += 8) {
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = col[(long long)(k + i) * F];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) fn(k + i, v[i]);
+  }
+  for (; k < bins; ++k) fn(k, col[(long long)k * F]);
+}
+
 // mode 0: centroid  sum(f S) / (sum S + eps)
 // mode 1: bandwidth (sum(S |f - c|^p) [/ (sum S + eps)])^(1/p), c = aux[row, frame]
 // mode 2: roll-off  f[first k with cumsum_k >= fraction * total], last bin if none
@@ -34,24 +48,20 @@ __global__ __launch_bounds__(256) void spectral_stat_kernel(
   float result = 0.0f;
   if (mode == 0) {
     float ws = 0.0f, ts = 0.0f;
-#pragma unroll 8
-    for (int k = 0; k < bins; ++k) {
-      const float v = col[(long long)k * F];
+    for_bins(col, bins, F, [&](int k, float v) {
       ws += freq[k] * v;
       ts += v;
-    }
+    });
     result = ws / (ts + kDivEps);
   } else if (mode == 1) {
     const float c = aux[g];
     float ws = 0.0f, ts = 0.0f;
-#pragma unroll 8
-    for (int k = 0; k < bins; ++k) {
-      const float v = col[(long long)k * F];
+    for_bins(col, bins, F, [&](int k, float v) {
       const float d = fabsf(freq[k] - c);
       const float dp = p == 2.0f ? d * d : (p == 1.0f ? d : powf(d, p));
       ws += v * dp;
       ts += v;
-    }
+    });
     if (norm) ws = ws / (ts + kDivEps);
     result = p == 2.0f ? sqrtf(ws) : (p == 1.0f ? ws : powf(ws, 1.0f / p));
   } else if (mode == 4) {
@@ -59,24 +69,20 @@ __global__ __launch_bounds__(256) void spectral_stat_kernel(
     // roll-off point; out is (rows, 4, frames) = centroid, bandwidth, roll-off, flatness, each
     // value what the single-statistic modes compute
     float ws = 0.0f, ts = 0.0f, ls = 0.0f, as = 0.0f;
-#pragma unroll 8
-    for (int k = 0; k < bins; ++k) {
-      const float v = col[(long long)k * F];
+    for_bins(col, bins, F, [&](int k, float v) {
       ws += freq[k] * v;
       ts += v;
       float u = pow_in(v, power_mode, power);
       u = u < amin ? amin : u;
       ls += logf(u);
       as += u;
-    }
+    });
     const float c = ws / (ts + kDivEps);
     const float thr = fraction * ts;
     float bw = 0.0f, cs = 0.0f;
     int hit = bins - 1;
     bool open = true;
-#pragma unroll 8
-    for (int k = 0; k < bins; ++k) {
-      const float v = col[(long long)k * F];
+    for_bins(col, bins, F, [&](int k, float v) {
       const float d = fabsf(freq[k] - c);
       bw += v * (p == 2.0f ? d * d : (p == 1.0f ? d : powf(d, p)));
       cs += v;
@@ -84,7 +90,7 @@ __global__ __launch_bounds__(256) void spectral_stat_kernel(
         hit = k;
         open = false;
       }
-    }
+    });
     if (norm) bw = bw / (ts + kDivEps);
     bw = p == 2.0f ? sqrtf(bw) : (p == 1.0f ? bw : powf(bw, 1.0f / p));
     float* __restrict__ o = out + row * 4 * F + f;
@@ -95,13 +101,12 @@ __global__ __launch_bounds__(256) void spectral_stat_kernel(
     return;
   } else {
     float ls = 0.0f, as = 0.0f;
-#pragma unroll 8
-    for (int k = 0; k < bins; ++k) {
-      float v = pow_in(col[(long long)k * F], power_mode, power);
+    for_bins(col, bins, F, [&](int, float s) {
+      float v = pow_in(s, power_mode, power);
       v = v < amin ? amin : v;  // a NaN stays a NaN, as in maximum(S, amin)
       ls += logf(v);
       as += v;
-    }
+    });
     result = expf(ls / (float)bins) / (as / (float)bins + kDivEps);
   }
   out[g] = result;
