@@ -199,9 +199,52 @@ __global__ __launch_bounds__(256) void spectral_rolloff_kernel(
 // Spectral contrast: per frame and band, the mean of the nq smallest (valley) and of the nq
 // largest (peak) values among bins lo .. hi-1, or the mean of all of them when nq >= hi - lo.
 // band[k] = {lo, hi, nq}; an empty band (hi <= lo) yields peak = valley = 0.  One thread per
-// frame keeps the K smallest and K largest values seen so far in two sorted register arrays
-// (K >= every nq) and pushes each bin through both with K min/max pairs.
+// frame keeps the K smallest and K largest values seen so far in two sorted register arrays and
+// pushes each bin through both with K min/max pairs; K is chosen per band (the smallest of 2, 3,
+// 4, 6, 8, 12 ... 64 that holds its nq: the narrow low bands select one or two values, only the
+// top band needs a long chain), rows are fetched four ahead of the chains.
 template <int K>
+__device__ __forceinline__ void contrast_select(const float* __restrict__ col, long long F, int lo,
+                                                int hi, int nq, float& peak, float& valley) {
+  float small[K], large[K];
+#pragma unroll
+  for (int i = 0; i < K; ++i) {
+    small[i] = INFINITY;
+    large[i] = -INFINITY;
+  }
+  auto push = [&](float v) {
+    float a = v, c = v;
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+      const float s0 = small[i], l0 = large[i];
+      small[i] = fminf(s0, a);
+      a = fmaxf(s0, a);
+      large[i] = fmaxf(l0, c);
+      c = fminf(l0, c);
+    }
+  };
+  int k = lo;
+  for (; k + 4 <= hi; k += 4) {
+    float v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = col[(long long)(k + i) * F];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) push(v[i]);
+  }
+  for (; k < hi; ++k) push(col[(long long)k * F]);
+  float vs = 0.0f, ps = 0.0f;
+#pragma unroll
+  for (int i = 0; i < K; ++i) {
+    if (i < nq) {
+      vs += small[i];
+      ps += large[i];
+    }
+  }
+  valley = vs / (float)nq;
+  peak = ps / (float)nq;
+}
+
+template <int KMAX>  // the chain length the widest quantile of the call needs (sets the register count)
 __global__ __launch_bounds__(256) void spectral_contrast_kernel(
     const float* __restrict__ S, long long rows, int bins, long long F, const int* __restrict__ band,
     int n_out, int linear, float* __restrict__ out) {
@@ -218,35 +261,18 @@ __global__ __launch_bounds__(256) void spectral_contrast_kernel(
         for (int k = lo; k < hi; ++k) sum += col[(long long)k * F];
         peak = valley = sum / (float)(hi - lo);
       } else {
-        float small[K], large[K];
-#pragma unroll
-        for (int i = 0; i < K; ++i) {
-          small[i] = INFINITY;
-          large[i] = -INFINITY;
-        }
-#pragma unroll 2
-        for (int k = lo; k < hi; ++k) {
-          const float v = col[(long long)k * F];
-          float a = v, c = v;
-#pragma unroll
-          for (int i = 0; i < K; ++i) {
-            const float s0 = small[i], l0 = large[i];
-            small[i] = fminf(s0, a);
-            a = fmaxf(s0, a);
-            large[i] = fmaxf(l0, c);
-            c = fminf(l0, c);
-          }
-        }
-        float vs = 0.0f, ps = 0.0f;
-#pragma unroll
-        for (int i = 0; i < K; ++i) {
-          if (i < nq) {
-            vs += small[i];
-            ps += large[i];
-          }
-        }
-        valley = vs / (float)nq;
-        peak = ps / (float)nq;
+        // the shortest chain of 2, 3, 4, 6, 8, 12, ... 64 that holds nq values
+        bool done = false;
+#define MIA_TRY(KK)                                                \
+  if constexpr (KMAX >= KK) {                                      \
+    if (!done && (nq <= KK || KMAX == KK)) {                       \
+      contrast_select<KK>(col, F, lo, hi, nq, peak, valley);       \
+      done = true;                                                 \
+    }                                                              \
+  }
+        MIA_TRY(2) MIA_TRY(3) MIA_TRY(4) MIA_TRY(6) MIA_TRY(8) MIA_TRY(12) MIA_TRY(16) MIA_TRY(24)
+        MIA_TRY(32) MIA_TRY(48) MIA_TRY(64)
+#undef MIA_TRY
       }
     }
     float r;
@@ -346,7 +372,8 @@ int mia_spectral_contrast(const float* S, int64_t rows, int bins, int64_t frames
 #define MIA_CONTRAST(KK)                                                                        \
   hipLaunchKernelGGL((spectral_contrast_kernel<KK>), grid, dim3(256), 0, s, S, (long long)rows, \
                      bins, (long long)frames, bands, n_bands_out, linear, out)
-  if (max_quantile <= 4) MIA_CONTRAST(4);
+  if (max_quantile <= 2) MIA_CONTRAST(2);
+  else if (max_quantile <= 4) MIA_CONTRAST(4);
   else if (max_quantile <= 8) MIA_CONTRAST(8);
   else if (max_quantile <= 16) MIA_CONTRAST(16);
   else if (max_quantile <= 32) MIA_CONTRAST(32);
