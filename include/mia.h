@@ -228,6 +228,9 @@ int mia_frame_signal(const float* x, int64_t B, int64_t T, int frame_length, int
  * minima: rows that do not reach below their floor are not touched a second time). */
 int mia_to_db(const float* x, int64_t B, int64_t n, float ref, float amin, float coef,
               float top_db, int per_clip, float* out, void* workspace, void* stream);
+/* primitives/convert.py:97-126 (db_to_power, divisor 10) and :166-195 (db_to_amplitude,
+ * divisor 20): out[i] = ref * 10^(x[i] / divisor), n values, one pass. */
+int mia_from_db(const float* x, int64_t n, float ref, float divisor, float* out, void* stream);
 /* _ext.dct (bindings.cpp:342-370, csrc/primitives/dct.cpp:103-159) along the
  * middle axis of x viewed as (outer, n_in, inner):
  *   out[o,k,i] = sum_n basis[k,n] * x[o,n,i];  basis: device, n_out x n_in. */

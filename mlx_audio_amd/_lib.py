@@ -91,6 +91,7 @@ SIGNATURES = {
     "mia_frame_signal": (c_int, [c_void_p, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p]),
     "mia_to_db": (c_int, [c_void_p, c_int64, c_int64, c_float, c_float, c_float, c_float, c_int,
                           c_void_p, c_void_p, c_void_p]),
+    "mia_from_db": (c_int, [c_void_p, c_int64, c_float, c_float, c_void_p, c_void_p]),
     "mia_dct2": (c_int, [c_void_p, c_int64, c_int, c_int64, c_void_p, c_int, c_void_p,
                          c_void_p]),
     "mia_magnitude": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),

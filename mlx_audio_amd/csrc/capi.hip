@@ -32,6 +32,7 @@ int launch_floor_clips(float*, long long, long long, int*, const int*, int, floa
 int launch_dct2(const float*, long long, int, long long, const float*, int, float*, const int*,
                 long long, float, hipStream_t);
 int launch_magnitude(const float2*, long long, float*, hipStream_t);
+int launch_from_db(const float*, long long, float, float, float*, hipStream_t);
 int launch_reduce_keys(int*, long long, hipStream_t);
 int launch_phase(const float2*, long long, float*, hipStream_t);
 
@@ -1126,6 +1127,14 @@ int mia_to_db(const float* x, int64_t B, int64_t n, float ref, float amin, float
     if (rc != MIA_OK) return rc;
   }
   return MIA_OK;
+}
+
+int mia_from_db(const float* x, int64_t n, float ref, float divisor, float* out, void* stream) {
+  MIA_REQUIRE(n >= 0, "negative length");
+  MIA_REQUIRE(divisor != 0.0f, "divisor must not be 0");
+  if (n == 0) return MIA_OK;
+  MIA_REQUIRE(x && out, "null pointer");
+  return launch_from_db(x, n, ref, divisor, out, (hipStream_t)stream);
 }
 
 int mia_dct2(const float* x, int64_t outer, int n_in, int64_t inner, const float* basis,

@@ -314,6 +314,85 @@ __global__ __launch_bounds__(256) void zcr_kernel(const float* __restrict__ y, l
   if (lane == 0) out[wave] = (float)count / (float)L;
 }
 
+// The same counts from one read of the signal.  A workgroup takes a run of consecutive frames of
+// one row; their samples form one span, cut into groups of 64.  A wave walks a contiguous quarter
+// of the groups, eight loads in flight: per group the ballot of the signs, xor-ed with itself
+// shifted by one sample (the carry is the last sign of the group before), is the mask of the
+// crossings; the mask and the wave's running count go to LDS.  A frame's count is then
+// P(last sample) - P(first sample), P(j) = crossings up to and including sample j of the span =
+// running count at the end of j's group minus the mask bits above j.  Integer counts: the result
+// equals zcr_kernel's bit for bit.
+constexpr int kZcrMaxGroups = 4096;
+__global__ __launch_bounds__(256) void zcr_span_kernel(const float* __restrict__ y, long long T, int L,
+                                                       int hop, long long pad, int pad_edge,
+                                                       int by_signbit, long long F, int frames_per_wg,
+                                                       float* __restrict__ out) {
+  extern __shared__ unsigned long long zcr_lds[];  // sized by the launch: 12 bytes per group
+  __shared__ int wave_total[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long row = blockIdx.y;
+  const long long f0 = (long long)blockIdx.x * frames_per_wg;
+  const int nf = (int)min((long long)frames_per_wg, F - f0);
+  const long long j0 = f0 * hop;                       // span start, in padded coordinates
+  const long long len = (long long)(nf - 1) * hop + L;  // samples of the span
+  const int n_g = (int)((len + 63) / 64);
+  const int gpw = (n_g + 3) / 4;                       // groups per wave
+  unsigned long long* const mask = zcr_lds;
+  // crossings of the wave's groups up to the end of this one; behind the masks of a full run
+  int* const upto = reinterpret_cast<int*>(zcr_lds + ((long long)(frames_per_wg - 1) * hop + L + 63) / 64);
+  const float* __restrict__ yr = y + row * T;
+  // sign of padded sample j0 + j: the load is unconditional (index clamped into the row, which is
+  // also what edge padding asks for), so that a batch of them can be in flight
+  auto sample_at = [&](long long j) {
+    const long long i = j0 + j - pad;
+    const float v = yr[i < 0 ? 0 : (i >= T ? T - 1 : i)];
+    return (pad_edge || (i >= 0 && i < T)) ? v : 0.0f;
+  };
+  auto positive = [&](float v) { return by_signbit ? (__float_as_uint(v) >> 31) == 0u : v >= 0.0f; };
+  const int g_begin = wave * gpw, g_end = min(g_begin + gpw, n_g);
+  // sign of the sample in front of the wave's first group (the span's first sample has none: its
+  // bit is never counted)
+  unsigned long long carry = 0;
+  if (g_begin < g_end && g_begin > 0) carry = positive(sample_at((long long)g_begin * 64 - 1)) ? 1ull : 0ull;
+  int run = 0;
+  for (int g = g_begin; g < g_end; g += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = sample_at((long long)(g + u) * 64 + lane);  // past the span: masked below
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (g + u < g_end) {
+        const unsigned long long b = __ballot(positive(v[u]));
+        const long long left = len - (long long)(g + u) * 64;  // samples of the span in this group
+        const unsigned long long valid = left >= 64 ? ~0ull : ((1ull << left) - 1ull);
+        const unsigned long long m = (b ^ ((b << 1) | carry)) & valid;
+        carry = b >> 63;
+        run += __popcll(m);
+        if (lane == 0) {
+          mask[g + u] = m;
+          upto[g + u] = run;
+        }
+      }
+    }
+  }
+  if (lane == 0) wave_total[wave] = run;
+  __syncthreads();
+  auto prefix = [&](long long j) {  // crossings at samples 0 .. j of the span (bit 0 of group 0 is garbage
+    const int g = (int)(j >> 6);    // and cancels: every frame subtracts a prefix that contains it)
+    const int w = g / gpw;
+    int base = upto[g];
+    for (int k = 0; k < w; ++k) base += wave_total[k];
+    const int bit = (int)(j & 63);
+    const unsigned long long above = bit == 63 ? 0ull : (mask[g] >> (bit + 1));
+    return base - __popcll(above);
+  };
+  for (int f = threadIdx.x; f < nf; f += 256) {
+    const long long s = (long long)f * hop;
+    const int count = prefix(s + L - 1) - prefix(s);
+    out[row * F + f0 + f] = (float)count / (float)L;
+  }
+}
+
 }  // namespace mia
 
 extern "C" {
@@ -395,6 +474,24 @@ int mia_zero_crossing_rate(const float* y, int64_t rows, int64_t n, int frame_le
   const long long F = 1 + (padded - frame_length) / hop_length;
   if (rows == 0) return MIA_OK;
   MIA_REQUIRE(y && out, "null pointer");
+  // one read of the signal where a run of frames fits the span kernel's tables
+  {
+    long long nf = 32768 / hop_length;
+    if (nf < 1) nf = 1;
+    if (nf > F) nf = F;
+    const long long groups = ((nf - 1) * hop_length + frame_length + 63) / 64;
+    if (groups <= kZcrMaxGroups && hop_length <= frame_length) {
+      constexpr int64_t kRowsPerLaunch = 65535;  // grid.y
+      for (int64_t r0 = 0; r0 < rows; r0 += kRowsPerLaunch) {
+        const int64_t nr = rows - r0 < kRowsPerLaunch ? rows - r0 : kRowsPerLaunch;
+        hipLaunchKernelGGL(zcr_span_kernel, dim3((unsigned)((F + nf - 1) / nf), (unsigned)nr), dim3(256),
+                           (size_t)groups * 12, (hipStream_t)stream, y + (size_t)r0 * n, (long long)n, frame_length, hop_length,
+                           pad, pad_edge, by_signbit, F, (int)nf, out + (size_t)r0 * F);
+        MIA_CHECK_HIP(hipGetLastError());
+      }
+      return MIA_OK;
+    }
+  }
   const long long waves = (long long)rows * F;
   if (waves > 0x7fffffffLL * 4) {
     set_error("%lld frames do not fit one launch (split the batch)", waves);

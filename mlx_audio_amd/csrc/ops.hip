@@ -125,6 +125,25 @@ __global__ __launch_bounds__(256) void to_db_kernel(const float* __restrict__ x,
   }
 }
 
+// out = ref * 10^(x / div): decibels back to power (div 10) or amplitude (div 20).
+__global__ __launch_bounds__(256) void from_db_kernel(const float* __restrict__ x, long long n, float ref,
+                                                       float div, float* __restrict__ out, int vec4) {
+  auto one = [&](float v) { return ref * exp10f(v / div); };
+  const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  if (vec4) {
+    const float4* __restrict__ x4 = reinterpret_cast<const float4*>(x);
+    float4* __restrict__ o4 = reinterpret_cast<float4*>(out);
+    for (long long i = tid; i < n / 4; i += stride) {
+      const float4 q = x4[i];
+      o4[i] = {one(q.x), one(q.y), one(q.z), one(q.w)};
+    }
+    for (long long i = (n / 4) * 4 + tid; i < n; i += stride) out[i] = one(x[i]);
+  } else {
+    for (long long i = tid; i < n; i += stride) out[i] = one(x[i]);
+  }
+}
+
 // keys[B] -> keys[B] holds max over all rows (one workgroup).
 __global__ __launch_bounds__(256) void reduce_keys_kernel(int* __restrict__ keys, long long B) {
   int k = kKeyMinusInf;
@@ -251,6 +270,16 @@ int launch_to_db(const float* x, long long B, long long n, float ref, float amin
                      clamp ? keys : nullptr, min_keys, vec4);
   MIA_CHECK_HIP(hipGetLastError());
   if (clamp) return launch_floor_clips(out, B, n, keys, min_keys, MIA_EPI_DB, top_db, per_clip, s);
+  return MIA_OK;
+}
+
+int launch_from_db(const float* x, long long n, float ref, float div, float* out, hipStream_t s) {
+  if (n <= 0) return MIA_OK;
+  const int vec4 = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+  long long bx = (n + 256 * 16 - 1) / (256 * 16);
+  if (bx > 65536) bx = 65536;
+  hipLaunchKernelGGL(from_db_kernel, dim3((unsigned)bx), dim3(256), 0, s, x, n, ref, div, out, vec4);
+  MIA_CHECK_HIP(hipGetLastError());
   return MIA_OK;
 }
 

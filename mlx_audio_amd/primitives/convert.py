@@ -55,11 +55,25 @@ def amplitude_to_db(S, ref=1.0, amin: float = 1e-5, top_db=80.0, per_clip: bool 
     return _to_db(S, ref, 20.0, amin, top_db, per_clip)
 
 
-def db_to_power(S_db: torch.Tensor, ref: float = 1.0) -> torch.Tensor:
+def _from_db(S_db, ref: float, divisor: float) -> torch.Tensor:
+    require_gpu()
+    if not isinstance(S_db, torch.Tensor):
+        S_db = torch.as_tensor(S_db)
+    if not S_db.is_cuda:
+        S_db = S_db.to("cuda")
+    S_db = S_db.to(torch.float32).contiguous()
+    out = torch.empty_like(S_db)
+    with torch.cuda.device(S_db.device):
+        _lib.check(_lib.lib().mia_from_db(S_db.data_ptr(), S_db.numel(), float(ref), float(divisor),
+                                          out.data_ptr(), stream_ptr(S_db.device)))
+    return out
+
+
+def db_to_power(S_db, ref: float = 1.0) -> torch.Tensor:
     """ref * 10^(S_db/10) (reference convert.py:97-126)."""
-    return ref * torch.pow(10.0, S_db / 10.0)
+    return _from_db(S_db, ref, 10.0)
 
 
-def db_to_amplitude(S_db: torch.Tensor, ref: float = 1.0) -> torch.Tensor:
+def db_to_amplitude(S_db, ref: float = 1.0) -> torch.Tensor:
     """ref * 10^(S_db/20) (reference convert.py:166-195)."""
-    return ref * torch.pow(10.0, S_db / 20.0)
+    return _from_db(S_db, ref, 20.0)

@@ -90,13 +90,16 @@ def test_statistics_from_a_waveform(gpu, n_fft, hop):
     assert (got != want).mean() <= 0.02
 
 
-@pytest.mark.parametrize("frame_length,hop", [(2048, 512), (256, 128), (100, 37), (1, 1)])
+@pytest.mark.parametrize("frame_length,hop", [(2048, 512), (256, 128), (100, 37), (1, 1), (64, 200), (9000, 33),
+                                              (300000, 1000), (65, 64), (4096, 4096)])
 def test_zero_crossing_rate_is_exact(gpu, frame_length, hop):
     rng = np.random.default_rng(frame_length)
     y = rng.standard_normal((3, 10000)).astype(np.float32)
     y[0, 100:200] = 0.0
     y[1, ::7] = -0.0
     for center in (True, False):
+        if not center and frame_length > y.shape[1]:
+            continue
         for pad_mode in ("edge", "constant"):
             for use_mlx in (True, False):
                 want = orc.zero_crossing_rate(y, frame_length, hop, center, pad_mode, use_mlx)
@@ -105,6 +108,20 @@ def test_zero_crossing_rate_is_exact(gpu, frame_length, hop):
                 np.testing.assert_array_equal(got.cpu().numpy(), want)
     np.testing.assert_array_equal(zero_crossing_rate(_dev(y[2], gpu), frame_length, hop).cpu().numpy(),
                                   orc.zero_crossing_rate(y[2], frame_length, hop))
+
+
+@pytest.mark.parametrize("frame_length,hop", [(2048, 512), (400, 160), (1024, 1000), (50, 7)])
+def test_zero_crossing_rate_over_long_rows(gpu, frame_length, hop):
+    """Rows long enough that several workgroups share one (their spans overlap by frame_length -
+    hop samples) and a span's groups of 64 samples do not line up with the row."""
+    rng = np.random.default_rng(hop)
+    y = rng.standard_normal((2, 150001)).astype(np.float32)
+    y[0, 70000:71000] = 0.0
+    y[1, 5::3] *= -0.0
+    for center, pad_mode in ((True, "edge"), (True, "constant"), (False, "edge")):
+        want = orc.zero_crossing_rate(y, frame_length, hop, center, pad_mode)
+        got = zero_crossing_rate(_dev(y, gpu), frame_length, hop, center, pad_mode)
+        np.testing.assert_array_equal(got.cpu().numpy(), want)
 
 
 @pytest.mark.parametrize("sr,n_fft,kw", [

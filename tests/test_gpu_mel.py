@@ -143,6 +143,31 @@ def test_power_to_db_and_friends(gpu):
                                np.maximum(S, 1e-5), rtol=1e-4)
 
 
+@pytest.mark.parametrize("shape", [(7,), (3, 64, 201), (5, 4099), (0, 12), (1, 1)])
+def test_db_to_power_and_amplitude_against_the_oracle(gpu, shape):
+    """One pass of ref * 10^(x / 10 | 20) (convert.py:97-126, 166-195): float32 round-off of the
+    oracle's power function (4e-6 relative: an exponent of up to 12 magnifies the last bit of the
+    quotient), non-finite values as IEEE has them, a view that is not contiguous, an odd element count (the float4 path's tail)."""
+    from mlx_audio_amd.primitives import db_to_amplitude, db_to_power
+
+    rng = np.random.default_rng(len(shape) + int(np.prod(shape)))
+    x = (rng.uniform(-120.0, 60.0, shape)).astype(np.float32)
+    if x.size >= 7:
+        x.reshape(-1)[:5] = [np.inf, -np.inf, np.nan, 0.0, -0.0]
+    xd = torch.from_numpy(x).to(gpu)
+    for fn, ofn in ((db_to_power, o.db_to_power), (db_to_amplitude, o.db_to_amplitude)):
+        for ref in (1.0, 0.25, 3.0):
+            got = fn(xd, ref=ref).cpu().numpy()
+            want = ofn(x, ref=ref)
+            assert got.shape == want.shape and got.dtype == np.float32
+            np.testing.assert_allclose(got, want, rtol=4e-6, atol=0, equal_nan=True)
+    if x.ndim == 3:
+        view = xd.transpose(1, 2)[:, 1:, :-1]
+        np.testing.assert_allclose(db_to_power(view).cpu().numpy(), o.db_to_power(view.cpu().numpy()),
+                                   rtol=4e-6, equal_nan=True)
+        np.testing.assert_allclose(db_to_power(x).cpu().numpy(), o.db_to_power(x), rtol=4e-6, equal_nan=True)
+
+
 def test_dct(gpu):
     import scipy.fft
 
