@@ -170,11 +170,13 @@ __global__ __launch_bounds__(WG, MIA_WAVE_OCC) void fwd_wave_kernel(FwdParams p,
         }
       } else if (interior && (reinterpret_cast<uintptr_t>(yb + s0) & 7) == 0) {
         const float2* __restrict__ src = reinterpret_cast<const float2*>(yb + s0);
+#pragma unroll 4
         for (int n = li; n < M; n += L) {
           const float2 x = src[n], w = win2[n];
           bufA[pos(n)] = {x.x * w.x, x.y * w.y};
         }
       } else if (interior) {
+#pragma unroll 4
         for (int n = li; n < M; n += L) {
           const float2 w = win2[n];
           bufA[pos(n)] = {yb[s0 + 2 * n] * w.x, yb[s0 + 2 * n + 1] * w.y};
@@ -202,6 +204,7 @@ __global__ __launch_bounds__(WG, MIA_WAVE_OCC) void fwd_wave_kernel(FwdParams p,
           }
         }
       }
+#pragma unroll 4
       for (int k = li; valid && packed && 2 * k <= M; k += L) {
         const float2 U = src[pos(k)];
         const float2 V = src[pos(k == 0 ? 0 : M - k)];
@@ -343,6 +346,7 @@ __global__ __launch_bounds__(WG, MIA_WAVE_OCC) void inv_wave_kernel(InvParams p,
     const long long b = valid ? fi / p.F : 0, f = valid ? fi - b * p.F : 0;
     const float2* __restrict__ xs = p.spec + b * p.sb + f * p.sf;
     if (valid && packed) {
+#pragma unroll 4
       for (int k = li; 2 * k <= M; k += L) {
         float2 xk = xs[(long long)k * p.sk], xm = xs[(long long)(M - k) * p.sk];
         if (k == 0) {
