@@ -529,7 +529,7 @@ int mia_plan_create(const mia_plan_desc* d, mia_plan** out) {
     if ((rc = upload(&p->d_row_len, len)) != MIA_OK) return fail(rc);
     if ((rc = upload(&p->d_row_off, off)) != MIA_OK) return fail(rc);
     if ((rc = upload(&p->d_wts, wts)) != MIA_OK) return fail(rc);
-    if (N == 400 && d->hop_length == 160 && d->power == 2.0f) {
+    if (N == 400 && d->hop_length == 160 && (d->power == 2.0f || d->power == 1.0f)) {
       rc = build_w400_tables(p, d->window, d->mel_basis, d->n_mels, bins);
       if (rc != MIA_OK) return fail(rc);
       if (p->d_sweep_meta != nullptr) p->w400_bank = w400_compiled_bank(d->mel_basis, d->n_mels, bins);
@@ -842,7 +842,10 @@ static int forward_mel_dispatch(const mia_plan* plan, const FwdParams& p, hipStr
                                 void* fft_ws = nullptr, size_t fft_ws_bytes = 0) {
   if (plan->wave_fft) return launch_forward_wave(plan, p, 1, s);
   if (plan->generic) return launch_forward_generic(plan, p, 1, fft_ws, fft_ws_bytes, s);
-  if (plan->d_sweep_meta != nullptr && p.n_mels * p.F < (1LL << 30)) {
+  // (magnitudes instead of powers: the n_fft = 400 kernel's linear and dB epilogues take them, its
+  // Whisper epilogue does not)
+  if (plan->d_sweep_meta != nullptr && p.n_mels * p.F < (1LL << 30) &&
+      (p.power_mode == 0 || (p.power_mode == 1 && p.epi != MIA_EPI_WHISPER))) {
     W400Tables tb{plan->d_win16, plan->d_tw16, plan->d_winp, plan->d_sweep_meta, plan->d_sweep_w,
                   plan->w400_bank, plan->opt_table_sweep, plan->opt_vgpr_staging, plan->cus,
                   plan->d_mfma_meta, plan->d_mfma_a, plan->opt_mfma_mel, plan->opt_dpp_pass2};

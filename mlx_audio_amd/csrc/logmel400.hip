@@ -487,6 +487,12 @@ __global__ __launch_bounds__(w400::WG, 4) void logmel400_kernel(
         if (!MIA_DBG(p, 2)) Dft<16>::run(v);  // (ablation: no pass-2 arithmetic)
 #pragma unroll
         for (int k2 = 0; k2 < 16; ++k2) pw[k2] = fmaf(v[k2].x, v[k2].x, v[k2].y * v[k2].y);
+        if constexpr (EPI != MIA_EPI_WHISPER) {
+          if (p.power_mode == 1) {  // power = 1: the filterbank is applied to magnitudes
+#pragma unroll
+            for (int k2 = 0; k2 < 16; ++k2) pw[k2] = sqrtf(pw[k2]);
+          }
+        }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       __builtin_amdgcn_wave_barrier();

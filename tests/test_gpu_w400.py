@@ -222,3 +222,32 @@ def test_paths_behind_the_headline_kernel_keep_parity():
     np.testing.assert_allclose(m.cpu().numpy(), want, rtol=1e-4, atol=1e-5 * want.max())
     db = power_to_db(m, top_db=80.0).cpu().numpy()
     assert np.abs(db - o.power_to_db(want, top_db=80.0)).max() <= 2e-3
+
+
+@pytest.mark.parametrize("n_mels", [40, 128])
+def test_magnitude_mel_on_the_n400_kernel(n_mels):
+    """power = 1 at n_fft 400 / hop 160 (onset strength at Whisper's framing, reference
+    onset.py:103-117): the n_fft = 400 kernel applies the filterbank to magnitudes.  Against the
+    oracle and against the generic plan the same call takes at hop 161."""
+    import oracle.spectral as o
+    from mlx_audio_amd._runtime import get_plan
+    from mlx_audio_amd.primitives import melspectrogram, onset_strength
+    from mlx_audio_amd.primitives.mel import mel_filterbank_np
+    from mlx_audio_amd.primitives.windows import padded_window_np
+    import oracle.onset as oo
+
+    rng = np.random.default_rng(n_mels)
+    y = rng.standard_normal((3, 48000)).astype(np.float32)
+    y[1] *= 1e-3
+    kw = dict(sr=16000, n_fft=400, hop_length=160, n_mels=n_mels, power=1.0)
+    got = melspectrogram(torch.from_numpy(y).cuda(), **kw).cpu().numpy()
+    want = o.melspectrogram(y, **kw)
+    for b in range(3):
+        np.testing.assert_allclose(got[b], want[b], rtol=1e-4, atol=2e-6 * want[b].max())
+    basis = mel_filterbank_np(16000, 400, n_mels, 0.0, 8000.0, False, "slaney")
+    plan = get_plan(torch.device("cuda", 0), 400, 160, True, "constant", padded_window_np("hann", 400, 400),
+                    mel_basis=basis, power=1.0)
+    assert _lib.lib().mia_plan_get_info(plan.handle, b"w400_tables") == 1
+    env = onset_strength(torch.from_numpy(y).cuda(), sr=16000, n_fft=400, hop_length=160, n_mels=n_mels).cpu().numpy()
+    np.testing.assert_allclose(env, oo.onset_strength(y, sr=16000, n_fft=400, hop_length=160, n_mels=n_mels),
+                               rtol=2e-3, atol=2e-5 * max(1.0, float(env.max())))
