@@ -284,6 +284,14 @@ __global__ __launch_bounds__(WG, C::OCC) void fwd_kernel(FwdParams p) {
     }
   }
 
+  // Statistics mode: the bin frequencies sit in LDS behind the magnitude tile (every frame reads
+  // all of them twice; from global memory that was a vector load per bin and lane).
+  float* const lds_freq = P + FT * PS;
+  if constexpr (MODE == 2) {
+    for (int i = tid; i <= M; i += WG) lds_freq[i] = p.freq[i];
+    __syncthreads();
+  }
+
   const long long total = p.B * p.tiles;
   const long long first = (long long)blockIdx.x * p.tiles_per_wg;
   const long long last = first + p.tiles_per_wg < total ? first + p.tiles_per_wg : total;
@@ -602,7 +610,7 @@ __global__ __launch_bounds__(WG, C::OCC) void fwd_kernel(FwdParams p) {
         for (int k = k0; k < k1; ++k) {
           const float v = pr[k];
           ts += v;
-          ws += p.freq[k] * v;
+          ws += lds_freq[k] * v;
           float u = p.flat_power == 2.0f ? v * v : (p.flat_power == 1.0f ? v : powf(v, p.flat_power));
           u = u < p.flat_amin ? p.flat_amin : u;
           ls += logf(u);
@@ -625,7 +633,7 @@ __global__ __launch_bounds__(WG, C::OCC) void fwd_kernel(FwdParams p) {
         const float centroid = ws / (total + 1e-8f);
         float bw = 0.0f;
         for (int k = k0; k < k1; ++k) {
-          const float d = fabsf(p.freq[k] - centroid);
+          const float d = fabsf(lds_freq[k] - centroid);
           const float dp = p.stat_p == 2.0f ? d * d : (p.stat_p == 1.0f ? d : powf(d, p.stat_p));
           bw += pr[k] * dp;
         }
@@ -656,7 +664,7 @@ __global__ __launch_bounds__(WG, C::OCC) void fwd_kernel(FwdParams p) {
           float* __restrict__ o = p.mout + (b * 4) * p.F + f0 + fl;
           o[0] = centroid;
           o[p.F] = bw;
-          o[2 * p.F] = p.freq[bin];
+          o[2 * p.F] = lds_freq[bin];
           o[3 * p.F] = expf(ls / (float)BINS) / (as / (float)BINS + 1e-8f);
         }
       }
@@ -847,6 +855,7 @@ static int launch_cfg(const FwdParams& p0, hipStream_t s) {
   p.tiles = (int)((p.F + FT - 1) / FT);
   constexpr bool TILE = MODE != 0 && MODE != 5;  // modes that keep a power / magnitude tile
   size_t lds = sizeof(float2) * G * C::LBUF + (TILE ? sizeof(float) * FT * PS : 0);
+  if (MODE == 2) lds += sizeof(float) * (C::M + 1);  // the bin frequencies
   if (MODE == 1 || MODE == 3) {
     // band tables ride along in LDS when two workgroups still fit a CU
     const size_t tables = sizeof(float) * (size_t)p.nnz + 3 * sizeof(int) * (size_t)p.n_mels;
