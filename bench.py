@@ -469,9 +469,11 @@ def main() -> None:
     # config.clock_warmup_ms.
     clock_warmup_ms = 30.0
     t_pre = time.perf_counter()
+    clock_warmup_steps = 0
     while (time.perf_counter() - t_pre) * 1e3 < clock_warmup_ms:
         out = step()
         torch.cuda.synchronize()
+        clock_warmup_steps += 1
     for _ in range(max(args.warmup, 1)):
         out = step()
     del out
@@ -543,7 +545,7 @@ def main() -> None:
             "data": "synthetic (random, generated on device; see config.workload)",
             "config": {"workload": desc, "clips_per_gpu": clips,
                        "parallelism": f"clips sharded over {n_gpus} GPU(s), no collective",
-                       "clock_warmup_ms": clock_warmup_ms},
+                       "clock_warmup_ms": clock_warmup_ms, "clock_warmup_steps": clock_warmup_steps},
             "roofline": {
                 "bound": "hbm",
                 "achieved": achieved,

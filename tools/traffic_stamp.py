@@ -39,10 +39,13 @@ def one_pass(workload, counter, out):
                 k = row["Kernel_Name"].split("(")[0][:70]
                 per_kernel[k][0] += 1
                 per_kernel[k][1] += float(row["Counter_Value"])
-    steps = min(n for n, _ in per_kernel.values())
-    detail = {k: {"kib_per_dispatch": v / n, "dispatches_per_step": n / steps}
-              for k, (n, v) in sorted(per_kernel.items())}
-    return sum(v for _, v in per_kernel.values()) / steps, detail, line
+    # calls of the step in this run: the untimed clock warm-up, the warm-up steps and the timed ones;
+    # a kernel's dispatches beyond a whole number per call belong to the workload's set-up
+    calls = line["config"]["clock_warmup_steps"] + max(line["warmup"], 1) + line["steps"]
+    detail = {k: {"kib_per_dispatch": v / n, "dispatches_per_step": n // calls}
+              for k, (n, v) in sorted(per_kernel.items()) if n // calls > 0}
+    total = sum(d["kib_per_dispatch"] * d["dispatches_per_step"] for d in detail.values())
+    return total, detail, line
 
 
 def main():
