@@ -265,6 +265,54 @@ __device__ __forceinline__ void super_step_any(int radix, float2* __restrict__ b
   }
 }
 
+// Bin kk (0 <= kk <= Nh) of the length-N real transform from the length-Nh transform Z of the
+// packed row: X = E + w^kk O, E = (Z[kk] + conj Z[Nh-kk])/2, O = -i (Z[kk] - conj Z[Nh-kk])/2.
+__device__ __forceinline__ float2 real_bin(const float2* __restrict__ Z, long long Nh, long long kk) {
+  const float2 a = Z[kk == Nh ? 0 : kk];
+  const float2 bz = Z[kk == 0 ? 0 : Nh - kk];
+  const float2 E = {0.5f * (a.x + bz.x), 0.5f * (a.y - bz.y)};
+  const float2 O = {0.5f * (a.y + bz.y), -0.5f * (a.x - bz.x)};
+  // exp(-2 pi i kk / N), N = 2 Nh: the quotient in double, its sine and cosine in float (the
+  // quotient's rounding to float moves the angle by at most 1e-7 rad, one float rounding of the
+  // twiddle; the double-precision sincospi was most of this kernel's time)
+  float s, c;
+  sincospif((float)(-(double)kk / (double)Nh), &s, &c);
+  const float2 wO = cmulf(O, float2{c, s});
+  return {E.x + wO.x, E.y + wO.y};
+}
+
+// The spectrum of a resampled row as input of its packed inverse transform.  Element k < Mh: the
+// two output-spectrum bins k and Mh-k (copied from the input spectrum below nyq, the shared
+// Nyquist bin scaled, zero above), combined into bin k of the packed inverse transform,
+// Z'[k] = (A + conj B) + i exp(2 pi i k / M) (A - conj B), conjugated (the inverse transform runs
+// as a forward one).
+struct ResizeIn {
+  const float2* Z;  // (rows, Nh): forward transform of the packed input rows
+  long long Nh, Mh, nyq, shared_bin;
+  float shared_scale;
+};
+__device__ __forceinline__ float2 resized_element(const ResizeIn& r, long long row, long long k) {
+  const float2* __restrict__ Z = r.Z + row * r.Nh;
+  auto bin = [&](long long kk) {
+    float2 X = {0.0f, 0.0f};
+    if (kk < r.nyq) {
+      X = real_bin(Z, r.Nh, kk);
+      if (kk == r.shared_bin) X = {X.x * r.shared_scale, X.y * r.shared_scale};
+      if (kk == 0 || kk == r.Mh) X.y = 0.0f;
+    }
+    return X;
+  };
+  const float2 A = bin(k);
+  const float2 B = bin(r.Mh - k);
+  const float2 S = {A.x + B.x, A.y - B.y};  // A + conj B
+  const float2 D = {A.x - B.x, A.y + B.y};  // A - conj B
+  float s, c;
+  sincospif((float)((double)k / (double)r.Mh), &s, &c);  // exp(+2 pi i k / M), M = 2 Mh
+  const float2 wD = cmulf(D, float2{c, s});
+  // Z' = S + i wD;  conj(Z')
+  return {S.x - wD.y, -(S.y + wD.x)};
+}
+
 // The elements c0, c0 + CSTEP, ... < R of one sequence, D apart, into registers.
 template <int PER, int CSTEP>
 __device__ __forceinline__ void super_fetch(float2 (&v)[PER], const float2* __restrict__ src, bool live,
@@ -276,9 +324,11 @@ __device__ __forceinline__ void super_fetch(float2 (&v)[PER], const float2* __re
   }
 }
 
+// out_scale != 0: the pass (the last of an inverse transform) stores conj(result) * out_scale - the
+// real output row, two samples per element.
 __global__ __launch_bounds__(kSuperThreads, 1) void stockham_super_kernel(
     const float2* __restrict__ in, float2* __restrict__ out, unsigned L, unsigned Ns, long long rows,
-    SuperPass sp, unsigned blocks_u, unsigned per_xcd, unsigned row_slots) {
+    SuperPass sp, unsigned blocks_u, unsigned per_xcd, unsigned row_slots, float out_scale) {
   extern __shared__ __attribute__((aligned(16))) unsigned char super_smem[];
   float2* buf = reinterpret_cast<float2*>(super_smem);   // [R][kSuperW]
   float2* table = buf + (size_t)sp.R * kSuperW;          // [R]
@@ -368,56 +418,20 @@ __global__ __launch_bounds__(kSuperThreads, 1) void stockham_super_kernel(
       const int slot = (k0 * r1 + k1) * r2 + k2;
       // not along k: ws is this thread's own w
       const unsigned ms = along_k ? (Ns == 1 ? 0u : us % Ns) : m;
-      dst[(size_t)(us - ms) * R + ms + (size_t)k * Ns] = buf[(size_t)slot * kSuperW + ws];
+      float2 res = buf[(size_t)slot * kSuperW + ws];
+      if (out_scale != 0.0f) res = {res.x * out_scale, -res.y * out_scale};
+      dst[(size_t)(us - ms) * R + ms + (size_t)k * Ns] = res;
     }
   }
 }
 
-// Bin kk (0 <= kk <= Nh) of the length-N real transform from the length-Nh transform Z of the
-// packed row: X = E + w^kk O, E = (Z[kk] + conj Z[Nh-kk])/2, O = -i (Z[kk] - conj Z[Nh-kk])/2.
-__device__ __forceinline__ float2 real_bin(const float2* __restrict__ Z, long long Nh, long long kk) {
-  const float2 a = Z[kk == Nh ? 0 : kk];
-  const float2 bz = Z[kk == 0 ? 0 : Nh - kk];
-  const float2 E = {0.5f * (a.x + bz.x), 0.5f * (a.y - bz.y)};
-  const float2 O = {0.5f * (a.y + bz.y), -0.5f * (a.x - bz.x)};
-  // exp(-2 pi i kk / N), N = 2 Nh: the quotient in double, its sine and cosine in float (the
-  // quotient's rounding to float moves the angle by at most 1e-7 rad, one float rounding of the
-  // twiddle; the double-precision sincospi was most of this kernel's time)
-  float s, c;
-  sincospif((float)(-(double)kk / (double)Nh), &s, &c);
-  const float2 wO = cmulf(O, float2{c, s});
-  return {E.x + wO.x, E.y + wO.y};
-}
-
-// One thread per k < Mh: the two output-spectrum bins k and Mh-k (copied from the input
-// spectrum below nyq, the shared Nyquist bin scaled, zero above), combined into bin k of the
-// packed inverse transform, Z'[k] = (A + conj B) + i exp(2 pi i k / M) (A - conj B), and stored
-// conjugated (the inverse transform runs as a forward one).
-__global__ void resize_packed_kernel(const float2* __restrict__ Zin, long long Nh, long long Mh,
-                                     long long rows, long long nyq, long long shared_bin,
-                                     float shared_scale, float2* __restrict__ Zout) {
+// One thread per element of the packed inverse transform's input (the plans whose first inverse
+// pass does not build its input itself).
+__global__ void resize_packed_kernel(ResizeIn r, long long rows, float2* __restrict__ Zout) {
   const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= rows * Mh) return;
-  const long long row = g / Mh, k = g - row * Mh;
-  const float2* __restrict__ Z = Zin + row * Nh;
-  auto bin = [&](long long kk) {
-    float2 X = {0.0f, 0.0f};
-    if (kk < nyq) {
-      X = real_bin(Z, Nh, kk);
-      if (kk == shared_bin) X = {X.x * shared_scale, X.y * shared_scale};
-      if (kk == 0 || kk == Mh) X.y = 0.0f;
-    }
-    return X;
-  };
-  const float2 A = bin(k);
-  const float2 B = bin(Mh - k);
-  const float2 S = {A.x + B.x, A.y - B.y};  // A + conj B
-  const float2 D = {A.x - B.x, A.y + B.y};  // A - conj B
-  float s, c;
-  sincospif((float)((double)k / (double)Mh), &s, &c);  // exp(+2 pi i k / M), M = 2 Mh
-  const float2 wD = cmulf(D, float2{c, s});
-  // Z' = S + i wD;  store conj(Z')
-  Zout[g] = {S.x - wD.y, -(S.y + wD.x)};
+  if (g >= rows * r.Mh) return;
+  const long long row = g / r.Mh, k = g - row * r.Mh;
+  Zout[g] = resized_element(r, row, k);
 }
 
 // y[2n] + i y[2n+1] = conj(F[n]) * scale.
@@ -559,8 +573,13 @@ static bool direct_ok(long long n_in, long long n_out) {
 
 // Forward FFT of `rows` rows of length L from `in` through the two buffers; `in` may be
 // bufB but not bufA.  *result = where the transform ends up (`in` itself when L == 1).
+// With super-passes the last step of the Fourier resampler rides along: the last pass writes
+// conj(result) * final_scale to `final_out` (*folded tells whether it did; the single-pass plans
+// leave that to unpack_real_kernel).
 static int fft_any(const float2* in, float2* bufA, float2* bufB, long long L, long long rows,
-                   hipStream_t s, const float2** result) {
+                   hipStream_t s, const float2** result, float2* final_out = nullptr,
+                   float final_scale = 0.0f, bool* folded = nullptr) {
+  if (folded) *folded = false;
   int radices[32];
   const int n = L > 1 ? plan_radices(L, radices) : 0;
   if (L > 1 && n == 0) {
@@ -580,12 +599,16 @@ static int fft_any(const float2* in, float2* bufA, float2* bufB, long long L, lo
   SuperPass sp[4];
   const int n_super = (n >= 4 && L >= 200000) ? plan_super(L, sp, 2) : 0;
   if (n_super > 0) {
+    const bool fold = final_out != nullptr;
     for (int i = 0; i < n_super; ++i) {
+      const bool last_final = fold && i == n_super - 1;
+      auto kern = stockham_super_kernel;
       const size_t lds = sizeof(float2) * (size_t)sp[i].R * (kSuperW + 1);
       if (lds > 64 * 1024) {
-        MIA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(stockham_super_kernel),
+        MIA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       }
+      if (last_final) dst = final_out;
       const unsigned D = (unsigned)(L / sp[i].R);
       // keep the grid around the size of the device when there are many rows: a workgroup
       // builds its twiddle table once and walks rows
@@ -593,14 +616,15 @@ static int fft_any(const float2* in, float2* bufA, float2* bufB, long long L, lo
       unsigned gys = gy;
       while (gys > 1 && (unsigned long long)gx * gys > kSuperGrid) gys = (gys + 1) / 2;
       const unsigned per_xcd = (gx + 7) / 8;
-      hipLaunchKernelGGL(stockham_super_kernel, dim3(8 * per_xcd * gys), dim3(kSuperThreads), lds, s,
-                         src, dst, (unsigned)L, Ns, rows, sp[i], gx, per_xcd, gys);
+      hipLaunchKernelGGL(kern, dim3(8 * per_xcd * gys), dim3(kSuperThreads), lds, s, src, dst,
+                         (unsigned)L, Ns, rows, sp[i], gx, per_xcd, gys, last_final ? final_scale : 0.0f);
       MIA_CHECK_HIP(hipGetLastError());
       Ns *= (unsigned)sp[i].R;
       src = dst;
       dst = dst == bufA ? bufB : bufA;
     }
     *result = src;
+    if (folded) *folded = fold;
     return MIA_OK;
   }
   for (int i = 0; i < n; ++i) {
@@ -1062,15 +1086,23 @@ int mia_resample_fft(const float* x, int64_t rows, int64_t n_in, int64_t n_out, 
       shared_bin = Nmin / 2;
       shared_scale = n_out < n_in ? 2.0f : 0.5f;
     }
-    hipLaunchKernelGGL(resize_packed_kernel, dim3(blocks_for(rows * Mh)), dim3(256), 0, sd, Z, Nh,
-                       Mh, (long long)rows, Nmin / 2 + 1, shared_bin, shared_scale, Zp);
+    const ResizeIn rz{Z, Nh, Mh, Nmin / 2 + 1, shared_bin, shared_scale};
+    const float out_scale = (float)((double)gain / (double)n_in);
+    hipLaunchKernelGGL(resize_packed_kernel, dim3(blocks_for(rows * Mh)), dim3(256), 0, sd, rz,
+                       (long long)rows, Zp);
     MIA_CHECK_HIP(hipGetLastError());
+    // Long rows: the last inverse super-pass writes the samples itself (no unpacking pass through
+    // memory).  Building the first pass's input from Z inside the pass as well was slower than
+    // this kernel plus a plain pass: 1.01 against 0.94 ms for 64 x 30 s 44.1 -> 16 kHz - four
+    // scattered loads and two sincos per element in a one-workgroup-per-CU kernel.
     const float2* F = nullptr;
-    rcd = fft_any(Zp, Zp == w0 ? w1 : w0, Zp, Mh, rows, sd, &F);
+    bool folded = false;
+    rcd = fft_any(Zp, Zp == w0 ? w1 : w0, Zp, Mh, rows, sd, &F, reinterpret_cast<float2*>(out), out_scale,
+                  &folded);
     if (rcd != MIA_OK) return rcd;
+    if (folded) return MIA_OK;
     hipLaunchKernelGGL(unpack_real_kernel, dim3(blocks_for(rows * Mh)), dim3(256), 0, sd, F,
-                       (long long)rows * Mh, (float)((double)gain / (double)n_in),
-                       reinterpret_cast<float2*>(out));
+                       (long long)rows * Mh, out_scale, reinterpret_cast<float2*>(out));
     MIA_CHECK_HIP(hipGetLastError());
     return MIA_OK;
   }
