@@ -298,3 +298,28 @@ def test_contrast_wide_quantile_bands():
     want = orc.spectral_contrast(S=S.cpu().numpy(), sr=44100, n_fft=2048, quantile=0.1)
     assert got.shape == want.shape
     assert np.allclose(got, want, rtol=2e-5, atol=2e-5)
+
+
+def test_full_size_zero_crossings_and_db_round_trip(gpu):
+    """1024 x 30 s @16 kHz through the span kernel: spot rows against the oracle bit for bit, and
+    the size-independent property that a positive scale changes no count; 492 M decibel values
+    back to powers and to decibels again."""
+    from mlx_audio_amd.primitives import db_to_power, power_to_db
+
+    g = torch.Generator(device=gpu)
+    g.manual_seed(11)
+    y = torch.randn((1024, 480000), generator=g, device=gpu)
+    z = zero_crossing_rate(y)
+    assert z.shape == (1024, 1, 938)
+    rows = [0, 511, 1023]
+    np.testing.assert_array_equal(z[rows].cpu().numpy(), orc.zero_crossing_rate(y[rows].cpu().numpy()))
+    assert torch.equal(zero_crossing_rate(y * 3.0), z)
+    z400 = zero_crossing_rate(y, frame_length=400, hop_length=160)
+    np.testing.assert_array_equal(z400[rows].cpu().numpy(),
+                                  orc.zero_crossing_rate(y[rows].cpu().numpy(), 400, 160))
+    del z, z400
+    S = torch.rand((512, 1025, 938), generator=g, device=gpu) * 100.0 + 1e-6
+    db = power_to_db(S, top_db=None)
+    back = db_to_power(db)
+    assert torch.allclose(back, S, rtol=2e-5, atol=0.0)
+    assert (power_to_db(back, top_db=None) - db).abs().max().item() <= 2e-5
