@@ -100,12 +100,68 @@ __device__ __forceinline__ const float2* transform(float2* bufA, float2* bufB, c
   return src;
 }
 
+// Plans compiled in: the framings of the reference's speech-enhancement model
+// (models/enhance/config.py:28-31, 63-68: n_fft 1920 and 640).  With the length, the radices and
+// the lanes per frame (64) known to the compiler the strides, twiddle steps and loop counts of
+// the passes are constants and a lane's loads of a frame are issued together; the run-time form
+// spends two thirds of its vector instructions on that arithmetic.  RuntimePlan: everything
+// from the kernel's arguments.
+struct RuntimePlan {
+  static constexpr int M = 0;
+};
+template <int M_, int R0_, int R1_, int R2_ = 1, int R3_ = 1>
+struct FixedPlan {
+  static constexpr int M = M_, R0 = R0_, R1 = R1_, R2 = R2_, R3 = R3_;
+  static_assert(R0_ * R1_ * R2_ * R3_ == M_, "radices multiply to the length");
+  static bool matches(const Passes& ps, int M, int L) {
+    const int want[4] = {R0_, R1_, R2_, R3_};
+    int n = 0;
+    while (n < 4 && want[n] > 1) ++n;
+    if (M != M_ || L != 64 || ps.n != n) return false;
+    for (int i = 0; i < n; ++i) {
+      if (ps.radix[i] != want[i]) return false;
+    }
+    return true;
+  }
+};
+using Plan960 = FixedPlan<960, 16, 15, 4>;  // n_fft 1920
+using Plan320 = FixedPlan<320, 8, 8, 5>;    // n_fft 640
+
+template <class PL>
+__device__ __forceinline__ const float2* transform_plan(float2* bufA, float2* bufB,
+                                                        const float2* __restrict__ twM, const Passes& ps,
+                                                        int M, int li, int L) {
+  if constexpr (PL::M == 0) {
+    return transform(bufA, bufB, twM, ps, M, li, L);
+  } else {
+    pass<PL::R0>(bufA, bufB, twM, PL::M, 1, 1.0f, li, 64);
+    wave_sync();
+    pass<PL::R1>(bufB, bufA, twM, PL::M, PL::R0, 1.0f / (float)PL::R0, li, 64);
+    wave_sync();
+    if constexpr (PL::R2 == 1) {
+      return bufA;
+    } else {
+      pass<PL::R2>(bufA, bufB, twM, PL::M, PL::R0 * PL::R1, 1.0f / (float)(PL::R0 * PL::R1), li, 64);
+      wave_sync();
+      if constexpr (PL::R3 == 1) {
+        return bufB;
+      } else {
+        pass<PL::R3>(bufB, bufA, twM, PL::M, PL::R0 * PL::R1 * PL::R2,
+                     1.0f / (float)(PL::R0 * PL::R1 * PL::R2), li, 64);
+        wave_sync();
+        return bufA;
+      }
+    }
+  }
+}
+
 #ifndef MIA_WAVE_OCC
 #define MIA_WAVE_OCC 3
 #endif
-template <int MODE>  // 0: spectrum rows, 1: mel (B, n_mels, F), 3: mel (B, F, n_mels)
-__global__ __launch_bounds__(WG, MIA_WAVE_OCC) void fwd_wave_kernel(FwdParams p, Passes ps, int M, int FPW,
-                                                                    int packed, int L) {
+template <int MODE, class PL>  // 0: spectrum rows, 1: mel (B, n_mels, F), 3: mel (B, F, n_mels)
+__global__ __launch_bounds__(WG, MIA_WAVE_OCC) void fwd_wave_kernel(FwdParams p, Passes ps, int M_arg, int FPW,
+                                                                    int packed_arg, int L_arg) {
+  const int M = PL::M ? PL::M : M_arg, packed = PL::M ? 1 : packed_arg, L = PL::M ? 64 : L_arg;
   // packed: n_fft is even, M = n_fft / 2 points z[n] = x[2 n] + i x[2 n + 1] and a split step;
   // else n_fft is odd, M = n_fft points with zero imaginary parts, bins 0 .. (M - 1) / 2 as they come.
   // L lanes per frame, GF = 64 / L frames side by side in a wave, FPW such rounds per tile.
@@ -189,7 +245,7 @@ __global__ __launch_bounds__(WG, MIA_WAVE_OCC) void fwd_wave_kernel(FwdParams p,
         }
       }
       wave_sync();
-      const float2* src = transform(bufA, bufB, twM, ps, M, li, L);
+      const float2* src = transform_plan<PL>(bufA, bufB, twM, ps, M, li, L);
       // ---- split step: bins k and M - k from Z[k] and Z[M - k] --------------------------------
       // E = U + conj(V);  O = -i (U - conj(V));  X[k] = (E + w O) / 2,  X[M - k] = conj(E - w O) / 2
       float2* __restrict__ crow = MODE == 0 ? p.cout + (b * p.F + f) * (long long)BINS : nullptr;
@@ -321,8 +377,11 @@ __global__ __launch_bounds__(WG, MIA_WAVE_OCC) void fwd_wave_kernel(FwdParams p,
 // E = (X[k] + conj X[M - k]) / 2, O = conj(w_k) (X[k] - conj X[M - k]) / 2, the inverse of the
 // forward kernel's split step; the imaginary parts of X[0] and X[n_fft / 2] are ignored, as
 // they are by the compiled plans.
-__global__ __launch_bounds__(WG, MIA_WAVE_OCC) void inv_wave_kernel(InvParams p, Passes ps, int M, int packed,
-                                                                    int L, long long frames_per_wg) {
+template <class PL>
+__global__ __launch_bounds__(WG, MIA_WAVE_OCC) void inv_wave_kernel(InvParams p, Passes ps, int M_arg,
+                                                                    int packed_arg, int L_arg,
+                                                                    long long frames_per_wg) {
+  const int M = PL::M ? PL::M : M_arg, packed = PL::M ? 1 : packed_arg, L = PL::M ? 64 : L_arg;
   const int GF = 64 / L;
   const int N = packed ? 2 * M : M;
   const int LB = buf_len(M);
@@ -373,7 +432,7 @@ __global__ __launch_bounds__(WG, MIA_WAVE_OCC) void inv_wave_kernel(InvParams p,
       }
     }
     wave_sync();
-    const float2* src = transform(bufA, bufB, twM, ps, M, li, L);
+    const float2* src = transform_plan<PL>(bufA, bufB, twM, ps, M, li, L);
     float* __restrict__ orow = p.frames + fi * (long long)N;
     if (valid && packed) {  // (x[2 n], x[2 n + 1]) = conj(y[n]) / (2 M): the sequence above was twice Z
       for (int n = li; n < M; n += L) {
@@ -528,7 +587,13 @@ int launch_forward_wave(const mia_plan* plan, const FwdParams& p0, int mode, hip
     set_error("n_fft=%d: %zu bytes of LDS", plan->n_fft, lds);
     return MIA_ERR_UNSUPPORTED;
   }
-  auto kern = kmode == 0 ? fwd_wave_kernel<0> : (kmode == 1 ? fwd_wave_kernel<1> : fwd_wave_kernel<3>);
+  auto pick = [&](auto plan_tag) {
+    using PL = decltype(plan_tag);
+    return kmode == 0 ? fwd_wave_kernel<0, PL> : (kmode == 1 ? fwd_wave_kernel<1, PL> : fwd_wave_kernel<3, PL>);
+  };
+  auto kern = pick(RuntimePlan{});
+  if (packed && Plan960::matches(ps, M, L)) kern = pick(Plan960{});
+  if (packed && Plan320::matches(ps, M, L)) kern = pick(Plan320{});
   if (lds > 64 * 1024) {
     MIA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -566,7 +631,9 @@ int launch_inverse_wave(const mia_plan* plan, const InvParams& p, hipStream_t s)
   const long long total = p.B * p.F;
   if (total <= 0) return MIA_OK;
   const size_t lds = sizeof(float2) * ((size_t)per_round * 2 * buf_len(M) + M);
-  auto kern = inv_wave_kernel;
+  auto kern = inv_wave_kernel<RuntimePlan>;
+  if (packed && Plan960::matches(ps, M, L)) kern = inv_wave_kernel<Plan960>;
+  if (packed && Plan320::matches(ps, M, L)) kern = inv_wave_kernel<Plan320>;
   if (lds > 64 * 1024) {
     MIA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
