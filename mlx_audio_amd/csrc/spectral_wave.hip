@@ -101,7 +101,7 @@ __device__ __forceinline__ const float2* transform(float2* bufA, float2* bufB, c
 }
 
 // Plans compiled in: the framings of the reference's speech-enhancement model
-// (models/enhance/config.py:28-31, 63-68: n_fft 1920 and 640).  With the length, the radices and
+// (models/enhance/config.py:28-31, 63-68: n_fft 1920 and 640) and two common speech framings.  With the length, the radices and
 // the lanes per frame (64) known to the compiler the strides, twiddle steps and loop counts of
 // the passes are constants and a lane's loads of a frame are issued together; the run-time form
 // spends two thirds of its vector instructions on that arithmetic.  RuntimePlan: everything
@@ -126,6 +126,8 @@ struct FixedPlan {
 };
 using Plan960 = FixedPlan<960, 16, 15, 4>;  // n_fft 1920
 using Plan320 = FixedPlan<320, 8, 8, 5>;    // n_fft 640
+using Plan480 = FixedPlan<480, 12, 10, 4>;  // n_fft 960: 20 ms at 48 kHz
+using Plan240 = FixedPlan<240, 5, 4, 4, 3>; // n_fft 480: 10 ms at 48 kHz, 30 ms at 16 kHz
 
 template <class PL>
 __device__ __forceinline__ const float2* transform_plan(float2* bufA, float2* bufB,
@@ -594,6 +596,8 @@ int launch_forward_wave(const mia_plan* plan, const FwdParams& p0, int mode, hip
   auto kern = pick(RuntimePlan{});
   if (packed && Plan960::matches(ps, M, L)) kern = pick(Plan960{});
   if (packed && Plan320::matches(ps, M, L)) kern = pick(Plan320{});
+  if (packed && Plan480::matches(ps, M, L)) kern = pick(Plan480{});
+  if (packed && Plan240::matches(ps, M, L)) kern = pick(Plan240{});
   if (lds > 64 * 1024) {
     MIA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -634,6 +638,8 @@ int launch_inverse_wave(const mia_plan* plan, const InvParams& p, hipStream_t s)
   auto kern = inv_wave_kernel<RuntimePlan>;
   if (packed && Plan960::matches(ps, M, L)) kern = inv_wave_kernel<Plan960>;
   if (packed && Plan320::matches(ps, M, L)) kern = inv_wave_kernel<Plan320>;
+  if (packed && Plan480::matches(ps, M, L)) kern = inv_wave_kernel<Plan480>;
+  if (packed && Plan240::matches(ps, M, L)) kern = inv_wave_kernel<Plan240>;
   if (lds > 64 * 1024) {
     MIA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
