@@ -101,33 +101,44 @@ __device__ __forceinline__ const float2* transform(float2* bufA, float2* bufB, c
 }
 
 // Plans compiled in: the framings of the reference's speech-enhancement model
-// (models/enhance/config.py:28-31, 63-68: n_fft 1920 and 640) and two common speech framings.  With the length, the radices and
-// the lanes per frame (64) known to the compiler the strides, twiddle steps and loop counts of
+// (models/enhance/config.py:28-31, 63-68: n_fft 1920 and 640) and common 44.1 / 48 kHz framings.  With the length, the radices and
+// the lanes per frame known to the compiler the strides, twiddle steps and loop counts of
 // the passes are constants and a lane's loads of a frame are issued together; the run-time form
 // spends two thirds of its vector instructions on that arithmetic.  RuntimePlan: everything
 // from the kernel's arguments.
 struct RuntimePlan {
-  static constexpr int M = 0;
+  static constexpr int M = 0, L = 0;
+  static constexpr bool PACKED = true;
 };
-template <int M_, int R0_, int R1_, int R2_ = 1, int R3_ = 1>
+// M points (n_fft / 2 packed, n_fft itself for an odd n_fft), L lanes per frame, radices.
+template <int M_, int L_, bool PACKED_, int R0_, int R1_, int R2_ = 1, int R3_ = 1>
 struct FixedPlan {
-  static constexpr int M = M_, R0 = R0_, R1 = R1_, R2 = R2_, R3 = R3_;
+  static constexpr int M = M_, L = L_, R0 = R0_, R1 = R1_, R2 = R2_, R3 = R3_;
+  static constexpr bool PACKED = PACKED_;
   static_assert(R0_ * R1_ * R2_ * R3_ == M_, "radices multiply to the length");
-  static bool matches(const Passes& ps, int M, int L) {
+  static bool matches(const Passes& ps, int M, int L, int packed) {
     const int want[4] = {R0_, R1_, R2_, R3_};
     int n = 0;
     while (n < 4 && want[n] > 1) ++n;
-    if (M != M_ || L != 64 || ps.n != n) return false;
+    if (M != M_ || L != L_ || (packed != 0) != PACKED_ || ps.n != n) return false;
     for (int i = 0; i < n; ++i) {
       if (ps.radix[i] != want[i]) return false;
     }
     return true;
   }
 };
-using Plan960 = FixedPlan<960, 16, 15, 4>;  // n_fft 1920
-using Plan320 = FixedPlan<320, 8, 8, 5>;    // n_fft 640
-using Plan480 = FixedPlan<480, 12, 10, 4>;  // n_fft 960: 20 ms at 48 kHz
-using Plan240 = FixedPlan<240, 5, 4, 4, 3>; // n_fft 480: 10 ms at 48 kHz, 30 ms at 16 kHz
+using Plan960 = FixedPlan<960, 64, true, 16, 15, 4>;   // n_fft 1920
+using Plan320 = FixedPlan<320, 64, true, 8, 8, 5>;     // n_fft 640
+using Plan480 = FixedPlan<480, 64, true, 12, 10, 4>;   // n_fft 960: 20 ms at 48 kHz
+using Plan240 = FixedPlan<240, 64, true, 5, 4, 4, 3>;  // n_fft 480: 10 ms at 48 kHz, 30 ms at 16 kHz
+using Plan441 = FixedPlan<441, 64, true, 7, 7, 3, 3>;  // n_fft 882: 20 ms at 44.1 kHz
+using Plan882 = FixedPlan<882, 64, true, 7, 7, 6, 3>;  // n_fft 1764: 40 ms at 44.1 kHz
+using Plan600 = FixedPlan<600, 64, true, 12, 10, 5>;   // n_fft 1200: 25 ms at 48 kHz
+using Plan768 = FixedPlan<768, 64, true, 16, 12, 4>;   // n_fft 1536: 32 ms at 48 kHz
+using Plan160 = FixedPlan<160, 16, true, 16, 10>;      // n_fft 320: 20 ms at 16 kHz, four frames side by side in a wave
+using Plan441u = FixedPlan<441, 64, false, 7, 7, 3, 3>;  // n_fft 441 (odd: unpacked): 10 ms at 44.1 kHz
+#define MIA_WAVE_FIXED_PLANS(X) \
+  X(Plan960) X(Plan320) X(Plan480) X(Plan240) X(Plan441) X(Plan882) X(Plan600) X(Plan768) X(Plan160) X(Plan441u)
 
 template <class PL>
 __device__ __forceinline__ const float2* transform_plan(float2* bufA, float2* bufB,
@@ -136,20 +147,20 @@ __device__ __forceinline__ const float2* transform_plan(float2* bufA, float2* bu
   if constexpr (PL::M == 0) {
     return transform(bufA, bufB, twM, ps, M, li, L);
   } else {
-    pass<PL::R0>(bufA, bufB, twM, PL::M, 1, 1.0f, li, 64);
+    pass<PL::R0>(bufA, bufB, twM, PL::M, 1, 1.0f, li, PL::L);
     wave_sync();
-    pass<PL::R1>(bufB, bufA, twM, PL::M, PL::R0, 1.0f / (float)PL::R0, li, 64);
+    pass<PL::R1>(bufB, bufA, twM, PL::M, PL::R0, 1.0f / (float)PL::R0, li, PL::L);
     wave_sync();
     if constexpr (PL::R2 == 1) {
       return bufA;
     } else {
-      pass<PL::R2>(bufA, bufB, twM, PL::M, PL::R0 * PL::R1, 1.0f / (float)(PL::R0 * PL::R1), li, 64);
+      pass<PL::R2>(bufA, bufB, twM, PL::M, PL::R0 * PL::R1, 1.0f / (float)(PL::R0 * PL::R1), li, PL::L);
       wave_sync();
       if constexpr (PL::R3 == 1) {
         return bufB;
       } else {
         pass<PL::R3>(bufB, bufA, twM, PL::M, PL::R0 * PL::R1 * PL::R2,
-                     1.0f / (float)(PL::R0 * PL::R1 * PL::R2), li, 64);
+                     1.0f / (float)(PL::R0 * PL::R1 * PL::R2), li, PL::L);
         wave_sync();
         return bufA;
       }
@@ -163,7 +174,7 @@ __device__ __forceinline__ const float2* transform_plan(float2* bufA, float2* bu
 template <int MODE, class PL>  // 0: spectrum rows, 1: mel (B, n_mels, F), 3: mel (B, F, n_mels)
 __global__ __launch_bounds__(WG, MIA_WAVE_OCC) void fwd_wave_kernel(FwdParams p, Passes ps, int M_arg, int FPW,
                                                                     int packed_arg, int L_arg) {
-  const int M = PL::M ? PL::M : M_arg, packed = PL::M ? 1 : packed_arg, L = PL::M ? 64 : L_arg;
+  const int M = PL::M ? PL::M : M_arg, packed = PL::M ? (PL::PACKED ? 1 : 0) : packed_arg, L = PL::M ? PL::L : L_arg;
   // packed: n_fft is even, M = n_fft / 2 points z[n] = x[2 n] + i x[2 n + 1] and a split step;
   // else n_fft is odd, M = n_fft points with zero imaginary parts, bins 0 .. (M - 1) / 2 as they come.
   // L lanes per frame, GF = 64 / L frames side by side in a wave, FPW such rounds per tile.
@@ -383,7 +394,7 @@ template <class PL>
 __global__ __launch_bounds__(WG, MIA_WAVE_OCC) void inv_wave_kernel(InvParams p, Passes ps, int M_arg,
                                                                     int packed_arg, int L_arg,
                                                                     long long frames_per_wg) {
-  const int M = PL::M ? PL::M : M_arg, packed = PL::M ? 1 : packed_arg, L = PL::M ? 64 : L_arg;
+  const int M = PL::M ? PL::M : M_arg, packed = PL::M ? (PL::PACKED ? 1 : 0) : packed_arg, L = PL::M ? PL::L : L_arg;
   const int GF = 64 / L;
   const int N = packed ? 2 * M : M;
   const int LB = buf_len(M);
@@ -594,10 +605,10 @@ int launch_forward_wave(const mia_plan* plan, const FwdParams& p0, int mode, hip
     return kmode == 0 ? fwd_wave_kernel<0, PL> : (kmode == 1 ? fwd_wave_kernel<1, PL> : fwd_wave_kernel<3, PL>);
   };
   auto kern = pick(RuntimePlan{});
-  if (packed && Plan960::matches(ps, M, L)) kern = pick(Plan960{});
-  if (packed && Plan320::matches(ps, M, L)) kern = pick(Plan320{});
-  if (packed && Plan480::matches(ps, M, L)) kern = pick(Plan480{});
-  if (packed && Plan240::matches(ps, M, L)) kern = pick(Plan240{});
+#define MIA_PICK(PLAN) \
+  if (PLAN::matches(ps, M, L, packed)) kern = pick(PLAN{});
+  MIA_WAVE_FIXED_PLANS(MIA_PICK)
+#undef MIA_PICK
   if (lds > 64 * 1024) {
     MIA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -636,10 +647,10 @@ int launch_inverse_wave(const mia_plan* plan, const InvParams& p, hipStream_t s)
   if (total <= 0) return MIA_OK;
   const size_t lds = sizeof(float2) * ((size_t)per_round * 2 * buf_len(M) + M);
   auto kern = inv_wave_kernel<RuntimePlan>;
-  if (packed && Plan960::matches(ps, M, L)) kern = inv_wave_kernel<Plan960>;
-  if (packed && Plan320::matches(ps, M, L)) kern = inv_wave_kernel<Plan320>;
-  if (packed && Plan480::matches(ps, M, L)) kern = inv_wave_kernel<Plan480>;
-  if (packed && Plan240::matches(ps, M, L)) kern = inv_wave_kernel<Plan240>;
+#define MIA_PICK(PLAN) \
+  if (PLAN::matches(ps, M, L, packed)) kern = inv_wave_kernel<PLAN>;
+  MIA_WAVE_FIXED_PLANS(MIA_PICK)
+#undef MIA_PICK
   if (lds > 64 * 1024) {
     MIA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -351,7 +351,7 @@ def test_any_length_plans_reject_the_entry_points_without_workspace(gpu):
     assert float(out.abs().max()) == 0.0
 
 
-WAVE_SIZES = [4, 6, 24, 98, 300, 320, 480, 640, 882, 960, 1200, 1536, 1764, 2000, 2016, 2048 - 2 * 7,
+WAVE_SIZES = [4, 6, 24, 98, 300, 320, 480, 640, 882, 960, 1200, 1536, 1764, 1920, 2000, 2016, 2048 - 2 * 7,
               3, 9, 105, 441, 675, 945,   # ... odd sizes, transformed unpacked
               8, 16, 32, 64, 128, 12, 18, 50]  # ... and short ones: several frames side by side in a wave
 
@@ -434,3 +434,25 @@ def test_istft_of_a_frames_contiguous_spectrum(gpu, n_fft, hop):
     assert torch.equal(torch.view_as_real(out), torch.view_as_real(S.transpose(1, 2).contiguous()))
     assert lib.mia_transpose_spectrum(Sc.data_ptr(), rows, S.shape[1], S.shape[2], Sc.data_ptr(), s) == _lib.MIA_ERR_INVALID
 
+
+
+@pytest.mark.parametrize("sr,n_fft,hop,win", [(48000, 1920, 480, 960), (16000, 640, 160, 320)])
+def test_enhance_model_framings_round_trip(gpu, sr, n_fft, hop, win):
+    """The framings of the reference's speech-enhancement model (models/enhance/config.py:28-31,
+    63-68; its _stft / _istft call stft and istft with a window half the FFT size, model.py:262-
+    291): they run on the per-wave transform's compiled-in plans.  Spectrum against the float64
+    oracle, and the inverse gives the signal back."""
+    from mlx_audio_amd.primitives import istft, stft
+
+    rng = np.random.default_rng(n_fft)
+    y = rng.standard_normal((3, sr // 2 + 17)).astype(np.float32)
+    yd = torch.from_numpy(y).to(gpu)
+    kw = dict(n_fft=n_fft, hop_length=hop, win_length=win, window="hann", center=True)
+    C = stft(yd, **kw)
+    want = o.stft(y.astype(np.float64), **kw)
+    scale = np.abs(want).max()
+    assert np.abs(C.cpu().numpy() - want).max() <= 3e-6 * scale
+    back = istft(C, hop_length=hop, win_length=win, n_fft=n_fft, window="hann", center=True, length=y.shape[1])
+    # the half-size window covers every sample twice (hop = win / 2): the round trip is exact to round-off
+    assert (back - yd).abs().max().item() <= 5e-6 * float(np.abs(y).max())
+    assert np.abs(back.cpu().numpy() - o.istft(want, hop_length=hop, win_length=win, n_fft=n_fft, length=y.shape[1])).max() <= 1e-5
