@@ -577,6 +577,10 @@ int mia_plan_set_option(mia_plan* plan, const char* key, int value) {
     plan->wave_fft = value != 0 && plan->generic && forward_wave_plan(plan->n_fft, &np, radix) ? 1 : 0;
     return MIA_OK;
   }
+  if (strcmp(key, "wave_istft_fused") == 0) {  // 0: inverse transform and overlap-add as two kernels again
+    plan->opt_two_kernel_istft = value == 0;
+    return MIA_OK;
+  }
   if (strcmp(key, "fwd_lane") == 0) {
     plan->opt_lane = value != 0;
     return MIA_OK;
@@ -755,13 +759,19 @@ int mia_overlap_add(const float* frames, const float* window, int64_t B, int64_t
   return MIA_OK;
 }
 
+// Inverse transform and overlap-add in one launch for this plan's framing?
+static bool plan_istft_fused(const mia_plan* plan) {
+  if (plan->wave_fft && plan->opt_two_kernel_istft) return false;
+  return mia::istft_fused_supported(plan->n_fft, plan->hop);
+}
+
 size_t mia_istft_workspace_bytes(const mia_plan* plan, int64_t B, int64_t F) {
   if (!plan || B <= 0 || F <= 0) return 0;
   if (plan->generic && !plan->wave_fft) {  // frames + the any-length engine's row buffers
     return align256(sizeof(float) * (size_t)B * (size_t)F * (size_t)plan->n_fft) +
            generic_fft_bytes(plan->n_fft, B * F);
   }
-  if (mia::istft_fused_supported(plan->n_fft, plan->hop)) return 0;  // overlap kept in LDS
+  if (plan_istft_fused(plan)) return 0;  // overlap kept in LDS
   return sizeof(float) * (size_t)B * (size_t)F * (size_t)plan->n_fft;
 }
 
@@ -792,7 +802,7 @@ int mia_istft(const mia_plan* plan, const void* spec, int64_t B, int64_t F, int6
     return mia_overlap_add(frames, plan->d_window, B, F, plan->n_fft, plan->hop, out_len, scale,
                            out, stream);
   }
-  if (mia::istft_fused_supported(plan->n_fft, plan->hop)) {
+  if (plan_istft_fused(plan)) {
     MIA_REQUIRE(B >= 0 && F >= 0 && out_len >= 0, "negative shape");
     MIA_REQUIRE((spec && out) || B == 0 || F == 0 || out_len == 0, "null buffer");
     if (B == 0 || out_len == 0) return MIA_OK;

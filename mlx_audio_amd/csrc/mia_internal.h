@@ -109,6 +109,7 @@ struct mia_plan {
   int opt_vgpr_staging = 0;      // mia_plan_set_option("w400_vgpr_staging"): ablation / test knob
   int opt_mfma_mel = 0;          // mia_plan_set_option("w400_mfma_mel"): A/B knob, matrix-core projection
   int opt_dpp_pass2 = 0;         // mia_plan_set_option("w400_dpp_pass2"): A/B knob, cross-lane (DPP) radix-16 pass
+  int opt_two_kernel_istft = 0;  // mia_plan_set_option("wave_istft_fused", 0): the per-wave inverse through its frame workspace (tests, A/B runs)
   int opt_lane = 0;              // mia_plan_set_option("fwd_lane"): A/B knob, frame-major mel rows at n_fft 1024 by
                                  // the wave-private kernel of spectral_lane.hip
   int* d_mfma_meta = nullptr;    // tables of that projection (n_mels <= 128)
@@ -210,6 +211,8 @@ int launch_forward(const mia_plan* plan, const FwdParams& p, int mode, hipStream
 int launch_inverse(const mia_plan* plan, const InvParams& p, hipStream_t s);
 bool istft_fused_supported(int n_fft, int hop);
 int launch_istft_fused(const mia_plan* plan, const InvParams& p, hipStream_t s);
+bool istft_wave_fused_supported(int n_fft, int hop);
+int launch_istft_wave_fused(const mia_plan* plan, const InvParams& p, hipStream_t s);
 int launch_init_keys(int* max_keys, int* min_keys, long long n, hipStream_t s);
 int launch_logmel400(const FwdParams& p, const W400Tables& tb, hipStream_t s);
 int w400_compiled_bank(const float* basis, int n_mels, int bins);

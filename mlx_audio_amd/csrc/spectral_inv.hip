@@ -653,9 +653,13 @@ static int launch_fused_own(const InvParams& p0, hipStream_t s) {
   return MIA_OK;
 }
 
-// The framings the fused kernel covers: hop = n_fft / 4 with hop a multiple of 256.
-bool istft_fused_supported(int n_fft, int hop) {
+// The framings a fused kernel covers: hop = n_fft / 4 with hop a multiple of 256 on the compiled
+// plans; the compiled-in plans of the per-wave transform at any hop from n_fft / 8 up.
+static bool istft_own_supported(int n_fft, int hop) {
   return (n_fft == 1024 || n_fft == 2048 || n_fft == 4096) && hop * 4 == n_fft;
+}
+bool istft_fused_supported(int n_fft, int hop) {
+  return istft_own_supported(n_fft, hop) || (!fft_size_supported(n_fft) && istft_wave_fused_supported(n_fft, hop));
 }
 
 int launch_istft_fused(const mia_plan* plan, const InvParams& p, hipStream_t s) {
@@ -664,6 +668,7 @@ int launch_istft_fused(const mia_plan* plan, const InvParams& p, hipStream_t s) 
     case 2048: return launch_fused_own<Inv2048, 4>(p, s);
     case 4096: return launch_fused_own<Inv4096, 4>(p, s);
     default:
+      if (istft_wave_fused_supported(plan->n_fft, p.hop)) return launch_istft_wave_fused(plan, p, s);
       set_error("n_fft=%d has no fused inverse", plan->n_fft);
       return MIA_ERR_UNSUPPORTED;
   }

@@ -459,6 +459,226 @@ __global__ __launch_bounds__(WG, MIA_WAVE_OCC) void inv_wave_kernel(InvParams p,
   }
 }
 
+// One pass of a compiled-in plan IN PLACE: a lane first reads the points of all its butterflies
+// (ceil(M / R / 64) of them), then writes their results to the natural-order slots of the same
+// buffer.  The frame belongs to one wave, whose LDS operations complete in order, so every read
+// of the pass precedes every write: half the LDS of a ping-pong pair.
+template <int R, int M, int NS>
+__device__ __forceinline__ void pass_inplace(float2* __restrict__ buf, const float2* __restrict__ twM, int li) {
+  constexpr int S = M / R, NB = (S + 63) / 64, tstep = S / NS;
+  float2 v[NB][R];
+  int base[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const int j = li + b * 64;
+    if (j < S) {
+      const int q = j / NS, jm = j - q * NS;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        float2 x = buf[pos(j + r * S)];
+        if (r > 0 && NS > 1) x = cmul(x, twM[jm * r * tstep]);
+        v[b][r] = x;
+      }
+      base[b] = q * NS * R + jm;
+    }
+  }
+  wave_sync();  // keeps the compiler from moving a write above another butterfly's reads
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    if (li + b * 64 < S) {
+      Dft<R>::run(v[b]);
+#pragma unroll
+      for (int r = 0; r < R; ++r) buf[pos(base[b] + r * NS)] = v[b][r];
+    }
+  }
+  wave_sync();
+}
+template <class PL>
+__device__ __forceinline__ void transform_inplace(float2* buf, const float2* __restrict__ twM, int li) {
+  pass_inplace<PL::R0, PL::M, 1>(buf, twM, li);
+  pass_inplace<PL::R1, PL::M, PL::R0>(buf, twM, li);
+  if constexpr (PL::R2 > 1) pass_inplace<PL::R2, PL::M, PL::R0 * PL::R1>(buf, twM, li);
+  if constexpr (PL::R3 > 1) pass_inplace<PL::R3, PL::M, PL::R0 * PL::R1 * PL::R2>(buf, twM, li);
+}
+
+// istft in one launch for the compiled-in plans (one frame per wave): inverse transform and
+// windowed overlap-add without the frame workspace (n_fft / hop times the signal, written and
+// read once by the two-kernel form).  A workgroup walks runs of consecutive frames of one row,
+// four frames (one per wave) a round.  After a round's transforms every thread takes samples of
+// the span the four frames cover, adds their windowed values to the sample's slot of an LDS ring
+// in ascending frame order - the order and the fused multiply-adds of ola_kernel, so the result
+// is bit-identical to the two-kernel form - and samples no later frame reaches are divided by
+// their window envelope and leave.  A run starts ceil(n_fft / hop) - 1 frames early (their
+// transforms are repeated) so that its first samples see all their frames.
+template <class PL>
+__global__ __launch_bounds__(WG, 2) void istft_wave_fused_kernel(InvParams p, int frames_per_run,
+                                                                 long long runs_per_row, long long total_runs,
+                                                                 long long runs_per_wg) {
+  constexpr int M = PL::M, N = 2 * M, LB = M + (M >> 4) + 2;  // LB = buf_len(M)
+  const int hop = p.hop;
+  const int RING = N + (WAVES - 1) * hop;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float2* const bufs = reinterpret_cast<float2*>(smem_raw);  // [WAVES][LB]
+  float2* const twM = bufs + WAVES * LB;                      // [M]
+  float2* const twH = twM + M;                                // [M / 2 + 1]
+  float* const win = reinterpret_cast<float*>(twH + M / 2 + 1);  // [N]
+  float* const acc = win + N;                                 // [RING]
+  float* const env = acc + RING;                              // [hop]: window envelope of a sample all of whose frames exist
+  const int tid = threadIdx.x, li = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int k = tid; k < M; k += WG) twM[k] = p.tw[2 * k];
+  for (int k = tid; k <= M / 2; k += WG) twH[k] = p.tw[k];
+  for (int k = tid; k < N; k += WG) win[k] = p.win[k];
+  // sum of w^2 over the frames that cover position r of a hop, in ascending frame order
+  // (descending position in the frame), as ola_kernel accumulates it
+  for (int r = tid; r < hop; r += WG) {
+    float wsum = 0.0f;
+    for (int n = r + ((N - 1 - r) / hop) * hop; n >= 0; n -= hop) {
+      const float wv = p.win[n];
+      wsum = fmaf(wv, wv, wsum);
+    }
+    env[r] = wsum;
+  }
+  float2* const buf = bufs + wave * LB;
+  const float inv_n = 1.0f / (float)N;
+  const int reach = (N + hop - 1) / hop - 1;  // earlier frames that reach into a frame's first samples
+  const long long run0 = (long long)blockIdx.x * runs_per_wg;
+  const long long run1 = run0 + runs_per_wg < total_runs ? run0 + runs_per_wg : total_runs;
+  for (long long run = run0; run < run1; ++run) {
+    const long long b = run / runs_per_row;
+    const long long fa = (run - b * runs_per_row) * frames_per_run;
+    const long long fb = fa + frames_per_run < p.F ? fa + frames_per_run : p.F;
+    const long long own_lo = fa * hop;
+    const long long own_hi = fb == p.F ? p.out_len : (fb * hop < p.out_len ? fb * hop : p.out_len);
+    const long long fstart = fa > reach ? fa - reach : 0;
+    __syncthreads();  // the previous run is done with the ring (and the tables are loaded)
+    for (int q = tid; q < RING; q += WG) acc[q] = 0.0f;
+    int origin = 0;  // ring slot of the round's first sample
+    float* __restrict__ orow = p.out + b * p.out_len;
+    for (long long f0 = fstart; f0 < fb; f0 += WAVES) {
+      const long long f = f0 + wave;
+      if (f < fb) {  // wave-uniform
+        const float2* __restrict__ xs = p.spec + b * p.sb + f * p.sf;
+#pragma unroll 4
+        for (int k = li; 2 * k <= M; k += 64) {
+          float2 xk = xs[(long long)k * p.sk], xm = xs[(long long)(M - k) * p.sk];
+          if (k == 0) {
+            xk.y = 0.0f;
+            xm.y = 0.0f;
+          }
+          const float2 w = twH[k];
+          const float2 E = {xk.x + xm.x, xk.y - xm.y};
+          const float2 D = {xk.x - xm.x, xk.y + xm.y};
+          const float2 O = {D.x * w.x + D.y * w.y, D.y * w.x - D.x * w.y};  // D conj(w)
+          buf[pos(k)] = {E.x - O.y, -(E.y + O.x)};
+          if (k != 0 && 2 * k != M) buf[pos(M - k)] = {E.x + O.y, E.y - O.x};
+        }
+        wave_sync();
+        transform_inplace<PL>(buf, twM, li);
+      }
+      __syncthreads();
+      const int nfr = fb - f0 < WAVES ? (int)(fb - f0) : WAVES;  // frames of this round
+      const bool final_round = f0 + WAVES >= fb;
+      const long long P0 = f0 * hop;
+      const int span = N + (nfr - 1) * hop;
+      float* __restrict__ obase = orow + P0;
+      // the round's samples this run owns, and those that are complete after it, as offsets from P0
+      const int lo_own = own_lo > P0 ? (int)(own_lo - P0 < span ? own_lo - P0 : span) : 0;
+      const int hi_own = own_hi > P0 ? (int)(own_hi - P0 < span ? own_hi - P0 : span) : 0;
+      const int emit_hi = final_round ? span : WAVES * hop;
+      // every sample of the round has all its frames (none clipped at the row's first or last frame)
+      const bool interior = P0 >= N - 1 && (P0 + span - 1) / hop <= p.F - 1;
+      auto envelope = [&](int j) {  // of a sample some of whose frames do not exist (the row's ends)
+        const long long s = P0 + j;
+        long long first = s - N + 1;
+        first = first <= 0 ? 0 : (first + hop - 1) / hop;
+        long long last = s / hop;
+        if (last > p.F - 1) last = p.F - 1;
+        float wsum = 0.0f;
+        for (long long ff = first; ff <= last; ++ff) {
+          const float wv = win[(int)(s - ff * hop)];
+          wsum = fmaf(wv, wv, wsum);
+        }
+        return wsum;
+      };
+      if ((hop & 1) == 0) {
+        // an even hop: a thread takes two neighbouring samples, which are the two halves of one
+        // complex point in every frame that covers them (ring, window and envelope read in pairs)
+        const float2* __restrict__ win2 = reinterpret_cast<const float2*>(win);
+        const float2* __restrict__ env2 = reinterpret_cast<const float2*>(env);
+        float2* __restrict__ acc2 = reinterpret_cast<float2*>(acc);
+        const int rstep = (2 * WG) % hop;
+        int r = (2 * tid) % hop;  // (P0 + j) mod hop: P0 is a multiple of hop
+        for (int j = 2 * tid; j < span; j += 2 * WG) {
+          int slot = origin + j;
+          if (slot >= RING) slot -= RING;
+          float2 sum = acc2[slot >> 1];
+#pragma unroll
+          for (int w = 0; w < WAVES; ++w) {
+            const int n = j - w * hop;
+            if (w < nfr && n >= 0 && n < N) {
+              const float2 y = bufs[w * LB + pos(n >> 1)];
+              const float2 wv = win2[n >> 1];
+              sum.x = fmaf(wv.x, y.x * inv_n, sum.x);
+              sum.y = fmaf(wv.y, -y.y * inv_n, sum.y);
+            }
+          }
+          if (j < emit_hi) {  // no later frame of the run reaches these samples
+            float2 ws = {0.0f, 0.0f};
+            if (interior) ws = env2[r >> 1];
+            if (j >= lo_own && j < hi_own) {
+              obase[j] = sum.x / fmaxf(interior ? ws.x : envelope(j), 1e-8f) * p.scale;
+            }
+            if (j + 1 >= lo_own && j + 1 < hi_own) {
+              obase[j + 1] = sum.y / fmaxf(interior ? ws.y : envelope(j + 1), 1e-8f) * p.scale;
+            }
+            acc2[slot >> 1] = {0.0f, 0.0f};
+          } else {
+            acc2[slot >> 1] = sum;
+          }
+          r += rstep;
+          if (r >= hop) r -= hop;
+        }
+      } else {
+        const int rstep = WG % hop;
+        int r = tid % hop;
+        for (int j = tid; j < span; j += WG) {
+          int slot = origin + j;
+          if (slot >= RING) slot -= RING;
+          float sum = acc[slot];
+#pragma unroll
+          for (int w = 0; w < WAVES; ++w) {
+            const int n = j - w * hop;
+            if (w < nfr && n >= 0 && n < N) {
+              const float2 y = bufs[w * LB + pos(n >> 1)];
+              const float x = (n & 1) ? -y.y * inv_n : y.x * inv_n;
+              sum = fmaf(win[n], x, sum);
+            }
+          }
+          if (j < emit_hi) {  // no later frame of the run reaches this sample
+            if (j >= lo_own && j < hi_own) {
+              obase[j] = sum / fmaxf(interior ? env[r] : envelope(j), 1e-8f) * p.scale;
+            }
+            acc[slot] = 0.0f;
+          } else {
+            acc[slot] = sum;
+          }
+          r += rstep;
+          if (r >= hop) r -= hop;
+        }
+      }
+      origin += WAVES * hop;
+      while (origin >= RING) origin -= RING;
+      __syncthreads();  // the next round overwrites the frames
+    }
+    // samples behind the last frame (an out_len beyond the frames' reach): no frame, zero
+    if (fb == p.F) {
+      const long long covered = (p.F - 1) * hop + N;
+      for (long long s = covered + tid; s < p.out_len; s += WG) orow[s] = 0.0f;
+    }
+  }
+}
+
 static size_t lds_bytes(int M, int bins, int L, int mode, int n_mels, int nnz, bool with_tables, int fpw) {
   const int gf = 64 / L;
   size_t b = sizeof(float2) * ((size_t)WAVES * gf * 2 * buf_len(M) + M);
@@ -668,6 +888,89 @@ int launch_inverse_wave(const mia_plan* plan, const InvParams& p, hipStream_t s)
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WG), lds, s, p, ps, M, packed, L, per_wg);
   MIA_CHECK_HIP(hipGetLastError());
   return MIA_OK;
+}
+
+// The framings istft_wave_fused_kernel serves: a compiled-in packed plan with one frame per wave,
+// at most eight frames over a sample, everything within the LDS of a CU.
+template <class PL>
+static bool wave_fused_fits(int n_fft, int hop) {
+  using namespace wavefft;
+  if constexpr (!(PL::PACKED && PL::L == 64)) {
+    return false;
+  } else {
+    return n_fft == 2 * PL::M && hop >= 1 && hop <= n_fft && (n_fft + hop - 1) / hop <= 8;
+  }
+}
+static size_t wave_fused_lds(int M, int hop) {
+  using namespace wavefft;
+  const int N = 2 * M;
+  return sizeof(float2) * ((size_t)WAVES * buf_len(M) + M + M / 2 + 1) +
+         sizeof(float) * ((size_t)N + N + (size_t)(WAVES - 1) * hop + hop);
+}
+
+bool istft_wave_fused_supported(int n_fft, int hop) {
+  using namespace wavefft;
+  Passes ps{};
+  int L = 64;
+  if (n_fft % 2 != 0 || !forward_wave_plan(n_fft, &ps.n, ps.radix, &L)) return false;
+  bool ok = false;
+#define MIA_FITS(PLAN) \
+  if (PLAN::matches(ps, n_fft / 2, L, 1) && wave_fused_fits<PLAN>(n_fft, hop)) ok = true;
+  MIA_WAVE_FIXED_PLANS(MIA_FITS)
+#undef MIA_FITS
+  return ok && wave_fused_lds(n_fft / 2, hop) <= 160 * 1024;
+}
+
+template <class PL>
+static int launch_wave_fused(const mia_plan* plan, const InvParams& p, hipStream_t s) {
+  using namespace wavefft;
+  if constexpr (!(PL::PACKED && PL::L == 64)) {
+    set_error("internal: plan has no fused inverse");
+    return MIA_ERR_UNSUPPORTED;
+  } else {
+    const size_t lds = wave_fused_lds(PL::M, p.hop);
+    auto kern = istft_wave_fused_kernel<PL>;
+    if (lds > 64 * 1024) {
+      MIA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    int per_cu = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), WG, lds) !=
+            hipSuccess || per_cu < 1) {
+      per_cu = 1;
+    }
+    // runs of 64 frames (the warm-up frames in front of a run are transformed twice: <= 5 %),
+    // shorter when that is what it takes to give every workgroup of the device a run
+    const long long want = (long long)(plan->cus > 0 ? plan->cus : 256) * per_cu;
+    long long fpr = 64;
+    while (fpr > 16 && p.B * ((p.F + fpr - 1) / fpr) < want) fpr /= 2;
+    const long long runs_per_row = (p.F + fpr - 1) / fpr;
+    const long long total = p.B * runs_per_row;
+    if (total <= 0) return MIA_OK;
+    long long grid = want < total ? want : total;
+    const long long per_wg = (total + grid - 1) / grid;
+    grid = (total + per_wg - 1) / per_wg;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WG), lds, s, p, (int)fpr, runs_per_row, total, per_wg);
+    MIA_CHECK_HIP(hipGetLastError());
+    return MIA_OK;
+  }
+}
+
+int launch_istft_wave_fused(const mia_plan* plan, const InvParams& p, hipStream_t s) {
+  using namespace wavefft;
+  Passes ps{};
+  int L = 64;
+  if (!forward_wave_plan(plan->n_fft, &ps.n, ps.radix, &L)) {
+    set_error("n_fft=%d is not served by the per-wave transform", plan->n_fft);
+    return MIA_ERR_UNSUPPORTED;
+  }
+#define MIA_GO(PLAN) \
+  if (PLAN::matches(ps, plan->n_fft / 2, L, 1) && wave_fused_fits<PLAN>(plan->n_fft, p.hop)) \
+    return launch_wave_fused<PLAN>(plan, p, s);
+  MIA_WAVE_FIXED_PLANS(MIA_GO)
+#undef MIA_GO
+  set_error("n_fft=%d hop=%d has no fused per-wave inverse", plan->n_fft, p.hop);
+  return MIA_ERR_UNSUPPORTED;
 }
 
 }  // namespace mia

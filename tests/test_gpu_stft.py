@@ -456,3 +456,53 @@ def test_enhance_model_framings_round_trip(gpu, sr, n_fft, hop, win):
     # the half-size window covers every sample twice (hop = win / 2): the round trip is exact to round-off
     assert (back - yd).abs().max().item() <= 5e-6 * float(np.abs(y).max())
     assert np.abs(back.cpu().numpy() - o.istft(want, hop_length=hop, win_length=win, n_fft=n_fft, length=y.shape[1])).max() <= 1e-5
+
+
+@pytest.mark.parametrize("n_fft,hop,win", [(1920, 480, 960), (640, 160, 320), (480, 120, 480), (960, 240, 960),
+                                           (882, 441, 882), (1200, 300, 1200), (1536, 192, 1536), (1764, 500, 1764),
+                                           (960, 480, 960), (480, 77, 300)])
+def test_fused_per_wave_inverse_equals_the_two_kernel_form(gpu, n_fft, hop, win):
+    """istft on the per-wave transform's compiled-in plans keeps the overlap in an LDS ring; the
+    same plan with option wave_istft_fused = 0 writes the frame workspace and runs the
+    overlap-add kernel.  Same overlap-add (additions in the same order, same envelope); the
+    transforms are two instantiations of the same passes (in place / between two buffers) whose
+    multiply-adds the compiler contracts differently, so the samples agree to float32 round-off
+    of the transform (3e-6 of the signal's peak), for rows long enough that a row is cut into
+    several runs, for one to three frames, for a requested length beyond the frames' reach and
+    for hops that do not divide the frame; and against the oracle."""
+    from mlx_audio_amd import _lib
+    from mlx_audio_amd._runtime import get_plan
+    from mlx_audio_amd.primitives import istft, stft
+    from mlx_audio_amd.primitives.windows import padded_window_np
+
+    lib = _lib.lib()
+    plan = get_plan(torch.device(gpu), n_fft, hop, True, "constant", padded_window_np("hann", win, n_fft))
+    rng = np.random.default_rng(n_fft + hop)
+    for rows, T in ((3, 100 * hop + 17), (2, 400 * hop + 5), (1, n_fft), (2, n_fft + hop), (300, 8 * hop + 1)):
+        y = rng.standard_normal((rows, T)).astype(np.float32)
+        C = stft(torch.from_numpy(y).to(gpu), n_fft=n_fft, hop_length=hop, win_length=win)
+        kw = dict(hop_length=hop, win_length=win, n_fft=n_fft)
+        assert lib.mia_istft_workspace_bytes(plan.handle, rows, C.shape[-1]) == 0
+        fused = [istft(C, length=L, **kw) for L in (T, None, T + 3 * n_fft)]
+        fused.append(istft(C, center=False, **kw))
+        _lib.check(lib.mia_plan_set_option(plan.handle, b"wave_istft_fused", 0))
+        try:
+            assert lib.mia_istft_workspace_bytes(plan.handle, rows, C.shape[-1]) > 0
+            two = [istft(C, length=L, **kw) for L in (T, None, T + 3 * n_fft)]
+            two.append(istft(C, center=False, **kw))
+        finally:
+            lib.mia_plan_set_option(plan.handle, b"wave_istft_fused", 1)
+        # Under a single window foot (the ends of an uncentred result, the tail of a length
+        # beyond the signal) the division by an envelope of 1e-4 .. 1e-8 magnifies the transforms'
+        # last bits: tight in the body, loose there.
+        tol = 3e-6 * float(np.abs(y).max())
+        for a, b in zip(fused, two):
+            assert a.shape == b.shape
+            if T > 3 * n_fft:
+                assert (a - b)[:, n_fft:T - n_fft].abs().max().item() <= tol
+            assert torch.allclose(a, b, rtol=2e-2, atol=1e-2)
+        assert (fused[0] - two[0]).abs().max().item() <= tol   # centred, cut to the signal: no foot at all
+        if rows <= 3 and hop * 2 <= win:   # the window overlaps itself: the signal comes back
+            want = o.istft(o.stft(y.astype(np.float64), n_fft=n_fft, hop_length=hop, win_length=win),
+                           hop_length=hop, win_length=win, n_fft=n_fft, length=T)
+            assert np.abs(fused[0].cpu().numpy() - want).max() <= 2e-5
