@@ -140,6 +140,50 @@ using Plan441u = FixedPlan<441, 64, false, 7, 7, 3, 3>;  // n_fft 441 (odd: unpa
 #define MIA_WAVE_FIXED_PLANS(X) \
   X(Plan960) X(Plan320) X(Plan480) X(Plan240) X(Plan441) X(Plan882) X(Plan600) X(Plan768) X(Plan160) X(Plan441u)
 
+// One pass of a compiled-in plan IN PLACE: a lane first reads the points of all its butterflies
+// (ceil(M / R / L) of them, L lanes per frame), then writes their results to the natural-order slots of the same
+// buffer.  The frame belongs to one wave, whose LDS operations complete in order, so every read
+// of the pass precedes every write: half the LDS of a ping-pong pair.
+template <int R, int M, int NS, int L>
+__device__ __forceinline__ void pass_inplace(float2* __restrict__ buf, const float2* __restrict__ twM, int li) {
+  constexpr int S = M / R, NB = (S + L - 1) / L, tstep = S / NS;
+  float2 v[NB][R];
+  int base[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const int j = li + b * L;
+    if (j < S) {
+      const int q = j / NS, jm = j - q * NS;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        float2 x = buf[pos(j + r * S)];
+        if (r > 0 && NS > 1) x = cmul(x, twM[jm * r * tstep]);
+        v[b][r] = x;
+      }
+      base[b] = q * NS * R + jm;
+    }
+  }
+  wave_sync();  // keeps the compiler from moving a write above another butterfly's reads
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    if (li + b * L < S) {
+      Dft<R>::run(v[b]);
+#pragma unroll
+      for (int r = 0; r < R; ++r) buf[pos(base[b] + r * NS)] = v[b][r];
+    }
+  }
+  wave_sync();
+}
+template <class PL>
+__device__ __forceinline__ void transform_inplace(float2* buf, const float2* __restrict__ twM, int li) {
+  pass_inplace<PL::R0, PL::M, 1, PL::L>(buf, twM, li);
+  pass_inplace<PL::R1, PL::M, PL::R0, PL::L>(buf, twM, li);
+  if constexpr (PL::R2 > 1) pass_inplace<PL::R2, PL::M, PL::R0 * PL::R1, PL::L>(buf, twM, li);
+  if constexpr (PL::R3 > 1) pass_inplace<PL::R3, PL::M, PL::R0 * PL::R1 * PL::R2, PL::L>(buf, twM, li);
+}
+
+// The passes of a frame: a compiled-in plan in place in bufA, the run-time form between bufA and
+// bufB; returns the buffer that holds the transform.
 template <class PL>
 __device__ __forceinline__ const float2* transform_plan(float2* bufA, float2* bufB,
                                                         const float2* __restrict__ twM, const Passes& ps,
@@ -147,24 +191,8 @@ __device__ __forceinline__ const float2* transform_plan(float2* bufA, float2* bu
   if constexpr (PL::M == 0) {
     return transform(bufA, bufB, twM, ps, M, li, L);
   } else {
-    pass<PL::R0>(bufA, bufB, twM, PL::M, 1, 1.0f, li, PL::L);
-    wave_sync();
-    pass<PL::R1>(bufB, bufA, twM, PL::M, PL::R0, 1.0f / (float)PL::R0, li, PL::L);
-    wave_sync();
-    if constexpr (PL::R2 == 1) {
-      return bufA;
-    } else {
-      pass<PL::R2>(bufA, bufB, twM, PL::M, PL::R0 * PL::R1, 1.0f / (float)(PL::R0 * PL::R1), li, PL::L);
-      wave_sync();
-      if constexpr (PL::R3 == 1) {
-        return bufB;
-      } else {
-        pass<PL::R3>(bufB, bufA, twM, PL::M, PL::R0 * PL::R1 * PL::R2,
-                     1.0f / (float)(PL::R0 * PL::R1 * PL::R2), li, PL::L);
-        wave_sync();
-        return bufA;
-      }
-    }
+    transform_inplace<PL>(bufA, twM, li);
+    return bufA;
   }
 }
 
@@ -186,8 +214,9 @@ __global__ __launch_bounds__(WG, MIA_WAVE_OCC) void fwd_wave_kernel(FwdParams p,
   const int LB = buf_len(M);
   const int PS = BINS | 1;  // odd row stride of the power tile
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  float2* const bufs = reinterpret_cast<float2*>(smem_raw);      // [WAVES][GF][2][LB]
-  float2* const twM = bufs + WAVES * GF * 2 * LB;                 // [M]
+  constexpr int NBUF = PL::M ? 1 : 2;                             // a compiled-in plan transforms in place
+  float2* const bufs = reinterpret_cast<float2*>(smem_raw);      // [WAVES][GF][NBUF][LB]
+  float2* const twM = bufs + WAVES * GF * NBUF * LB;              // [M]
   float* const P = reinterpret_cast<float*>(twM + M);             // [FT][PS] (mel modes)
   float* const lds_wts = P + (MEL ? FT * PS : 0);
   int* const lds_rows = reinterpret_cast<int*>(lds_wts + (MEL ? p.nnz : 0));
@@ -208,8 +237,8 @@ __global__ __launch_bounds__(WG, MIA_WAVE_OCC) void fwd_wave_kernel(FwdParams p,
   }
   __syncthreads();
 
-  float2* const bufA = bufs + (wave * GF + g) * 2 * LB;
-  float2* const bufB = bufA + LB;
+  float2* const bufA = bufs + (wave * GF + g) * NBUF * LB;
+  float2* const bufB = bufA + (NBUF - 1) * LB;
   const float2* __restrict__ win2 = reinterpret_cast<const float2*>(p.win);
   const float half_scale = 0.5f * p.scale;
 
@@ -399,15 +428,16 @@ __global__ __launch_bounds__(WG, MIA_WAVE_OCC) void inv_wave_kernel(InvParams p,
   const int N = packed ? 2 * M : M;
   const int LB = buf_len(M);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  float2* const bufs = reinterpret_cast<float2*>(smem_raw);  // [WAVES][GF][2][LB]
-  float2* const twM = bufs + WAVES * GF * 2 * LB;             // [M]
+  constexpr int NBUF = PL::M ? 1 : 2;                         // a compiled-in plan transforms in place
+  float2* const bufs = reinterpret_cast<float2*>(smem_raw);  // [WAVES][GF][NBUF][LB]
+  float2* const twM = bufs + WAVES * GF * NBUF * LB;          // [M]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & (L - 1), g = lane / L;
   for (int k = tid; k < M; k += WG) twM[k] = p.tw[packed ? 2 * k : k];
   __syncthreads();
-  float2* const bufA = bufs + (wave * GF + g) * 2 * LB;
-  float2* const bufB = bufA + LB;
+  float2* const bufA = bufs + (wave * GF + g) * NBUF * LB;
+  float2* const bufB = bufA + (NBUF - 1) * LB;
   const long long total = p.B * p.F;
   const long long first = (long long)blockIdx.x * frames_per_wg;
   const long long last = first + frames_per_wg < total ? first + frames_per_wg : total;
@@ -457,48 +487,6 @@ __global__ __launch_bounds__(WG, MIA_WAVE_OCC) void inv_wave_kernel(InvParams p,
     }
     wave_sync();  // the next round overwrites the buffers
   }
-}
-
-// One pass of a compiled-in plan IN PLACE: a lane first reads the points of all its butterflies
-// (ceil(M / R / 64) of them), then writes their results to the natural-order slots of the same
-// buffer.  The frame belongs to one wave, whose LDS operations complete in order, so every read
-// of the pass precedes every write: half the LDS of a ping-pong pair.
-template <int R, int M, int NS>
-__device__ __forceinline__ void pass_inplace(float2* __restrict__ buf, const float2* __restrict__ twM, int li) {
-  constexpr int S = M / R, NB = (S + 63) / 64, tstep = S / NS;
-  float2 v[NB][R];
-  int base[NB];
-#pragma unroll
-  for (int b = 0; b < NB; ++b) {
-    const int j = li + b * 64;
-    if (j < S) {
-      const int q = j / NS, jm = j - q * NS;
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        float2 x = buf[pos(j + r * S)];
-        if (r > 0 && NS > 1) x = cmul(x, twM[jm * r * tstep]);
-        v[b][r] = x;
-      }
-      base[b] = q * NS * R + jm;
-    }
-  }
-  wave_sync();  // keeps the compiler from moving a write above another butterfly's reads
-#pragma unroll
-  for (int b = 0; b < NB; ++b) {
-    if (li + b * 64 < S) {
-      Dft<R>::run(v[b]);
-#pragma unroll
-      for (int r = 0; r < R; ++r) buf[pos(base[b] + r * NS)] = v[b][r];
-    }
-  }
-  wave_sync();
-}
-template <class PL>
-__device__ __forceinline__ void transform_inplace(float2* buf, const float2* __restrict__ twM, int li) {
-  pass_inplace<PL::R0, PL::M, 1>(buf, twM, li);
-  pass_inplace<PL::R1, PL::M, PL::R0>(buf, twM, li);
-  if constexpr (PL::R2 > 1) pass_inplace<PL::R2, PL::M, PL::R0 * PL::R1>(buf, twM, li);
-  if constexpr (PL::R3 > 1) pass_inplace<PL::R3, PL::M, PL::R0 * PL::R1 * PL::R2>(buf, twM, li);
 }
 
 // istft in one launch for the compiled-in plans (one frame per wave): inverse transform and
@@ -679,9 +667,10 @@ __global__ __launch_bounds__(WG, 2) void istft_wave_fused_kernel(InvParams p, in
   }
 }
 
-static size_t lds_bytes(int M, int bins, int L, int mode, int n_mels, int nnz, bool with_tables, int fpw) {
+static size_t lds_bytes(int M, int bins, int L, int mode, int n_mels, int nnz, bool with_tables, int fpw,
+                        int nbuf) {
   const int gf = 64 / L;
-  size_t b = sizeof(float2) * ((size_t)WAVES * gf * 2 * buf_len(M) + M);
+  size_t b = sizeof(float2) * ((size_t)WAVES * gf * nbuf * buf_len(M) + M);
   if (mode != 0) {
     b += sizeof(float) * (size_t)(WAVES * fpw * gf) * (bins | 1);
     if (with_tables) b += sizeof(float) * (size_t)nnz + 3 * sizeof(int) * (size_t)n_mels;
@@ -766,6 +755,17 @@ bool forward_wave_plan(int n_fft, int* n_pass, int radix[6], int* lanes_per_fram
   return true;
 }
 
+// Buffers per frame: one for a compiled-in plan (its passes run in place), two otherwise.
+static int wave_buffers(const wavefft::Passes& ps, int M, int L, int packed) {
+  using namespace wavefft;
+  int nbuf = 2;
+#define MIA_HAS(PLAN) \
+  if (PLAN::matches(ps, M, L, packed)) nbuf = 1;
+  MIA_WAVE_FIXED_PLANS(MIA_HAS)
+#undef MIA_HAS
+  return nbuf;
+}
+
 // Frame-major rows leave through the FFT buffers: a tile's n_mels x frames values must fit them
 // (true for every long transform; short ones, which put many frames into a tile, only with few bands).
 bool forward_wave_frame_major_ok(int n_fft, int n_mels) {
@@ -775,7 +775,7 @@ bool forward_wave_frame_major_ok(int n_fft, int n_mels) {
   const int M = n_fft % 2 == 0 ? n_fft / 2 : n_fft;
   const size_t gf = 64 / l;
   return n_mels % 4 == 0 && sizeof(float) * (size_t)(WAVES * MAXFPW) * gf * n_mels <=
-                                sizeof(float2) * (size_t)WAVES * gf * 2 * buf_len(M);
+                                sizeof(float2) * (size_t)WAVES * gf * buf_len(M);  // (one buffer per frame: what every plan has)
 }
 
 int launch_forward_wave(const mia_plan* plan, const FwdParams& p0, int mode, hipStream_t s) {
@@ -797,9 +797,10 @@ int launch_forward_wave(const mia_plan* plan, const FwdParams& p0, int mode, hip
   }
   // Frames per wave and tile: two (a tile of eight frames: 32-byte runs of a mel row), or one
   // where that lets a second workgroup onto the CU (long transforms with a power tile).
+  const int nbuf = wave_buffers(ps, M, L, packed);
   int fpw = MAXFPW;
-  if (kmode != 0 && lds_bytes(M, bins, L, kmode, p.n_mels, p.nnz, false, 2) > 80 * 1024 &&
-      lds_bytes(M, bins, L, kmode, p.n_mels, p.nnz, false, 1) <= 80 * 1024) {
+  if (kmode != 0 && lds_bytes(M, bins, L, kmode, p.n_mels, p.nnz, false, 2, nbuf) > 80 * 1024 &&
+      lds_bytes(M, bins, L, kmode, p.n_mels, p.nnz, false, 1, nbuf) <= 80 * 1024) {
     fpw = 1;
   }
   const int FT = WAVES * fpw * (64 / L);
@@ -810,10 +811,10 @@ int launch_forward_wave(const mia_plan* plan, const FwdParams& p0, int mode, hip
     set_error("%lld tiles do not fit one launch (split the batch)", total);
     return MIA_ERR_UNSUPPORTED;
   }
-  size_t lds = lds_bytes(M, bins, L, kmode, p.n_mels, p.nnz, false, fpw);
+  size_t lds = lds_bytes(M, bins, L, kmode, p.n_mels, p.nnz, false, fpw, nbuf);
   p.lds_tables = 0;
-  if (kmode != 0 && lds_bytes(M, bins, L, kmode, p.n_mels, p.nnz, true, fpw) <= 80 * 1024) {
-    lds = lds_bytes(M, bins, L, kmode, p.n_mels, p.nnz, true, fpw);  // band tables ride along while two workgroups fit a CU
+  if (kmode != 0 && lds_bytes(M, bins, L, kmode, p.n_mels, p.nnz, true, fpw, nbuf) <= 80 * 1024) {
+    lds = lds_bytes(M, bins, L, kmode, p.n_mels, p.nnz, true, fpw, nbuf);  // band tables ride along while two workgroups fit a CU
     p.lds_tables = 1;
   }
   if (lds > 160 * 1024) {
@@ -865,7 +866,7 @@ int launch_inverse_wave(const mia_plan* plan, const InvParams& p, hipStream_t s)
   const int per_round = WAVES * (64 / L);  // frames a workgroup takes at a time
   const long long total = p.B * p.F;
   if (total <= 0) return MIA_OK;
-  const size_t lds = sizeof(float2) * ((size_t)per_round * 2 * buf_len(M) + M);
+  const size_t lds = sizeof(float2) * ((size_t)per_round * wave_buffers(ps, M, L, packed) * buf_len(M) + M);
   auto kern = inv_wave_kernel<RuntimePlan>;
 #define MIA_PICK(PLAN) \
   if (PLAN::matches(ps, M, L, packed)) kern = inv_wave_kernel<PLAN>;
