@@ -100,6 +100,9 @@ __device__ __forceinline__ const float2* transform(float2* bufA, float2* bufB, c
   return src;
 }
 
+#ifndef MIA_WAVE_OCC
+#define MIA_WAVE_OCC 3
+#endif
 // Plans compiled in: the framings of the reference's speech-enhancement model
 // (models/enhance/config.py:28-31, 63-68: n_fft 1920 and 640) and common 44.1 / 48 kHz framings.  With the length, the radices and
 // the lanes per frame known to the compiler the strides, twiddle steps and loop counts of
@@ -107,13 +110,14 @@ __device__ __forceinline__ const float2* transform(float2* bufA, float2* bufB, c
 // spends two thirds of its vector instructions on that arithmetic.  RuntimePlan: everything
 // from the kernel's arguments.
 struct RuntimePlan {
-  static constexpr int M = 0, L = 0;
+  static constexpr int M = 0, L = 0, OCC = MIA_WAVE_OCC;
   static constexpr bool PACKED = true;
 };
 // M points (n_fft / 2 packed, n_fft itself for an odd n_fft), L lanes per frame, radices.
-template <int M_, int L_, bool PACKED_, int R0_, int R1_, int R2_ = 1, int R3_ = 1>
+template <int M_, int L_, bool PACKED_, int R0_, int R1_, int R2_ = 1, int R3_ = 1, int OCC_ = MIA_WAVE_OCC>
 struct FixedPlan {
   static constexpr int M = M_, L = L_, R0 = R0_, R1 = R1_, R2 = R2_, R3 = R3_;
+  static constexpr int OCC = OCC_;  // waves per SIMD the register budget is for
   static constexpr bool PACKED = PACKED_;
   static_assert(R0_ * R1_ * R2_ * R3_ == M_, "radices multiply to the length");
   static bool matches(const Passes& ps, int M, int L, int packed) {
@@ -127,12 +131,12 @@ struct FixedPlan {
     return true;
   }
 };
-using Plan960 = FixedPlan<960, 64, true, 16, 15, 4>;   // n_fft 1920
+using Plan960 = FixedPlan<960, 64, true, 16, 15, 4, 1, 2>;  // n_fft 1920 (spills under the budget of three waves)
 using Plan320 = FixedPlan<320, 64, true, 8, 8, 5>;     // n_fft 640
 using Plan480 = FixedPlan<480, 64, true, 12, 10, 4>;   // n_fft 960: 20 ms at 48 kHz
 using Plan240 = FixedPlan<240, 64, true, 5, 4, 4, 3>;  // n_fft 480: 10 ms at 48 kHz, 30 ms at 16 kHz
 using Plan441 = FixedPlan<441, 64, true, 7, 7, 3, 3>;  // n_fft 882: 20 ms at 44.1 kHz
-using Plan882 = FixedPlan<882, 64, true, 7, 7, 6, 3>;  // n_fft 1764: 40 ms at 44.1 kHz
+using Plan882 = FixedPlan<882, 64, true, 7, 7, 6, 3, 2>;  // n_fft 1764: 40 ms at 44.1 kHz (0.45 -> 0.34 ms with the budget of two waves)
 using Plan600 = FixedPlan<600, 64, true, 12, 10, 5>;   // n_fft 1200: 25 ms at 48 kHz
 using Plan768 = FixedPlan<768, 64, true, 16, 12, 4>;   // n_fft 1536: 32 ms at 48 kHz
 using Plan160 = FixedPlan<160, 16, true, 16, 10>;      // n_fft 320: 20 ms at 16 kHz, four frames side by side in a wave
@@ -196,11 +200,8 @@ __device__ __forceinline__ const float2* transform_plan(float2* bufA, float2* bu
   }
 }
 
-#ifndef MIA_WAVE_OCC
-#define MIA_WAVE_OCC 3
-#endif
 template <int MODE, class PL>  // 0: spectrum rows, 1: mel (B, n_mels, F), 3: mel (B, F, n_mels)
-__global__ __launch_bounds__(WG, MIA_WAVE_OCC) void fwd_wave_kernel(FwdParams p, Passes ps, int M_arg, int FPW,
+__global__ __launch_bounds__(WG, PL::OCC) void fwd_wave_kernel(FwdParams p, Passes ps, int M_arg, int FPW,
                                                                     int packed_arg, int L_arg) {
   const int M = PL::M ? PL::M : M_arg, packed = PL::M ? (PL::PACKED ? 1 : 0) : packed_arg, L = PL::M ? PL::L : L_arg;
   // packed: n_fft is even, M = n_fft / 2 points z[n] = x[2 n] + i x[2 n + 1] and a split step;
@@ -420,7 +421,7 @@ __global__ __launch_bounds__(WG, MIA_WAVE_OCC) void fwd_wave_kernel(FwdParams p,
 // forward kernel's split step; the imaginary parts of X[0] and X[n_fft / 2] are ignored, as
 // they are by the compiled plans.
 template <class PL>
-__global__ __launch_bounds__(WG, MIA_WAVE_OCC) void inv_wave_kernel(InvParams p, Passes ps, int M_arg,
+__global__ __launch_bounds__(WG, PL::OCC) void inv_wave_kernel(InvParams p, Passes ps, int M_arg,
                                                                     int packed_arg, int L_arg,
                                                                     long long frames_per_wg) {
   const int M = PL::M ? PL::M : M_arg, packed = PL::M ? (PL::PACKED ? 1 : 0) : packed_arg, L = PL::M ? PL::L : L_arg;
