@@ -506,3 +506,42 @@ def test_fused_per_wave_inverse_equals_the_two_kernel_form(gpu, n_fft, hop, win)
             want = o.istft(o.stft(y.astype(np.float64), n_fft=n_fft, hop_length=hop, win_length=win),
                            hop_length=hop, win_length=win, n_fft=n_fft, length=T)
             assert np.abs(fused[0].cpu().numpy() - want).max() <= 2e-5
+
+
+def test_fused_per_wave_inverse_random_framings(gpu):
+    """Thirty random framings on the compiled-in per-wave plans (hop anywhere from n_fft / 8 to
+    n_fft, window anywhere up to n_fft, row counts and lengths at random, centred or not, a
+    strided spectrum): fused inverse against the float64 oracle wherever the window envelope is
+    not tiny, and against the two-kernel form's shape."""
+    from mlx_audio_amd.primitives import istft, stft
+
+    rng = np.random.default_rng(2026)
+    sizes = [320, 480, 640, 882, 960, 1200, 1536, 1764, 1920]
+    for case in range(30):
+        n_fft = int(rng.choice(sizes))
+        hop = int(rng.integers(max(1, n_fft // 8), n_fft // 2 + 1))
+        win = int(rng.integers(max(2 * hop, n_fft // 4), n_fft + 1))
+        rows = int(rng.integers(1, 6))
+        T = int(rng.integers(n_fft, 40 * n_fft))
+        center = bool(rng.integers(0, 2))
+        y = rng.standard_normal((rows, T)).astype(np.float32)
+        kw = dict(n_fft=n_fft, hop_length=hop, win_length=win, center=center)
+        C = stft(torch.from_numpy(y).to(gpu), **kw)
+        if case % 3 == 0:   # frames contiguous, as the reference lays its spectrum out
+            C = C.contiguous()
+        want = o.istft(o.stft(y.astype(np.float64), **kw), hop_length=hop, win_length=win, n_fft=n_fft,
+                       center=center, length=T if center else None)
+        got = istft(C, hop_length=hop, win_length=win, n_fft=n_fft, center=center,
+                    length=T if center else None).cpu().numpy()
+        assert got.shape == want.shape, (case, n_fft, hop, win, rows, T, center)
+        # where at least one window of the sum is not near its foot the two agree to round-off
+        w = o.get_window("hann", win)
+        env = np.zeros(n_fft + hop * (C.shape[-1] - 1))
+        pw = np.zeros(n_fft)
+        pw[(n_fft - win) // 2:(n_fft - win) // 2 + win] = w ** 2
+        for f in range(C.shape[-1]):
+            env[f * hop:f * hop + n_fft] += pw
+        env = env[n_fft // 2:n_fft // 2 + want.shape[1]] if center else env[:want.shape[1]]
+        ok = env > 1e-2
+        assert ok.mean() > 0.5
+        assert np.abs(got - want)[:, ok].max() <= 2e-4, (case, n_fft, hop, win, rows, T, center)
