@@ -607,6 +607,7 @@ __global__ __launch_bounds__(WG, C::OCC) void fwd_kernel(FwdParams p) {
       for (int fl = tid >> 6; fl < fcount; fl += WG / 64) {
         const float* __restrict__ pr = P + fl * PS;
         float ts = 0.0f, ws = 0.0f, ls = 0.0f, as = 0.0f;
+#pragma unroll 6
         for (int k = k0; k < k1; ++k) {
           const float v = pr[k];
           ts += v;
@@ -632,6 +633,7 @@ __global__ __launch_bounds__(WG, C::OCC) void fwd_kernel(FwdParams p) {
         }
         const float centroid = ws / (total + 1e-8f);
         float bw = 0.0f;
+#pragma unroll 6
         for (int k = k0; k < k1; ++k) {
           const float d = fabsf(lds_freq[k] - centroid);
           const float dp = p.stat_p == 2.0f ? d * d : (p.stat_p == 1.0f ? d : powf(d, p.stat_p));
