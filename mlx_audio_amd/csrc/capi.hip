@@ -761,8 +761,12 @@ int mia_overlap_add(const float* frames, const float* window, int64_t B, int64_t
 
 // Inverse transform and overlap-add in one launch for this plan's framing?
 static bool plan_istft_fused(const mia_plan* plan) {
-  if (plan->wave_fft && plan->opt_two_kernel_istft) return false;
-  return mia::istft_fused_supported(plan->n_fft, plan->hop);
+  if (mia::istft_fused_supported(plan->n_fft, plan->hop)) {
+    return !(plan->wave_fft && plan->opt_two_kernel_istft);
+  }
+  // the small compiled sizes: their inverse on the per-wave transform's fused kernel
+  return !plan->generic && !plan->opt_two_kernel_istft &&
+         mia::istft_wave_fused_supported(plan->n_fft, plan->hop);
 }
 
 size_t mia_istft_workspace_bytes(const mia_plan* plan, int64_t B, int64_t F) {
@@ -824,7 +828,10 @@ int mia_istft(const mia_plan* plan, const void* spec, int64_t B, int64_t F, int6
     p.out_len = out_len;
     p.scale = scale;
     p.out = out;
-    return launch_istft_fused(plan, p, (hipStream_t)stream);
+    if (mia::istft_fused_supported(plan->n_fft, plan->hop)) {
+      return launch_istft_fused(plan, p, (hipStream_t)stream);
+    }
+    return launch_istft_wave_fused(plan, p, (hipStream_t)stream);  // a compiled size on an inverse-only plan
   }
   MIA_REQUIRE(workspace_bytes >= mia_istft_workspace_bytes(plan, B, F),
               "workspace too small: %zu < %zu", workspace_bytes,

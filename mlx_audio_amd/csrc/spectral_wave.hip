@@ -141,6 +141,18 @@ using Plan600 = FixedPlan<600, 64, true, 12, 10, 5>;   // n_fft 1200: 25 ms at 4
 using Plan768 = FixedPlan<768, 64, true, 16, 12, 4>;   // n_fft 1536: 32 ms at 48 kHz
 using Plan160 = FixedPlan<160, 16, true, 16, 10>;      // n_fft 320: 20 ms at 16 kHz, four frames side by side in a wave
 using Plan441u = FixedPlan<441, 64, false, 7, 7, 3, 3>;  // n_fft 441 (odd: unpacked): 10 ms at 44.1 kHz
+// The small sizes with a compiled multi-wave forward plan have no fused inverse of their own
+// (inverse transform, frame workspace, overlap-add kernel: 1.1 - 1.7 ms for 256 x 30 s); their
+// istft runs on these one-wave-per-frame plans instead (always 64 lanes per frame: the fused
+// kernel's layout).
+using Inv128 = FixedPlan<128, 64, true, 4, 4, 8>;    // n_fft 256
+using Inv200 = FixedPlan<200, 64, true, 5, 5, 8>;    // n_fft 400
+using Inv256w = FixedPlan<256, 64, true, 4, 8, 8>;   // n_fft 512
+using Inv400w = FixedPlan<400, 64, true, 5, 8, 10>;  // n_fft 800
+// (1024 and 2048 points at a hop other than n_fft / 4, which their own fused kernel does not take)
+using Inv512w = FixedPlan<512, 64, true, 8, 8, 8>;           // n_fft 1024
+using Inv1024w = FixedPlan<1024, 64, true, 16, 16, 4, 1, 2>;  // n_fft 2048
+#define MIA_WAVE_INVERSE_ONLY_PLANS(X) X(Inv128) X(Inv200) X(Inv256w) X(Inv400w) X(Inv512w) X(Inv1024w)
 #define MIA_WAVE_FIXED_PLANS(X) \
   X(Plan960) X(Plan320) X(Plan480) X(Plan240) X(Plan441) X(Plan882) X(Plan600) X(Plan768) X(Plan160) X(Plan441u)
 
@@ -912,14 +924,20 @@ static size_t wave_fused_lds(int M, int hop) {
 
 bool istft_wave_fused_supported(int n_fft, int hop) {
   using namespace wavefft;
-  Passes ps{};
-  int L = 64;
-  if (n_fft % 2 != 0 || !forward_wave_plan(n_fft, &ps.n, ps.radix, &L)) return false;
+  if (n_fft % 2 != 0) return false;
   bool ok = false;
 #define MIA_FITS(PLAN) \
-  if (PLAN::matches(ps, n_fft / 2, L, 1) && wave_fused_fits<PLAN>(n_fft, hop)) ok = true;
-  MIA_WAVE_FIXED_PLANS(MIA_FITS)
+  if (wave_fused_fits<PLAN>(n_fft, hop)) ok = true;
+  MIA_WAVE_INVERSE_ONLY_PLANS(MIA_FITS)
 #undef MIA_FITS
+  Passes ps{};
+  int L = 64;
+  if (!ok && forward_wave_plan(n_fft, &ps.n, ps.radix, &L)) {
+#define MIA_FITS(PLAN) \
+  if (PLAN::matches(ps, n_fft / 2, L, 1) && wave_fused_fits<PLAN>(n_fft, hop)) ok = true;
+    MIA_WAVE_FIXED_PLANS(MIA_FITS)
+#undef MIA_FITS
+  }
   return ok && wave_fused_lds(n_fft / 2, hop) <= 160 * 1024;
 }
 
@@ -960,6 +978,10 @@ static int launch_wave_fused(const mia_plan* plan, const InvParams& p, hipStream
 
 int launch_istft_wave_fused(const mia_plan* plan, const InvParams& p, hipStream_t s) {
   using namespace wavefft;
+#define MIA_GO(PLAN) \
+  if (wave_fused_fits<PLAN>(plan->n_fft, p.hop)) return launch_wave_fused<PLAN>(plan, p, s);
+  MIA_WAVE_INVERSE_ONLY_PLANS(MIA_GO)
+#undef MIA_GO
   Passes ps{};
   int L = 64;
   if (!forward_wave_plan(plan->n_fft, &ps.n, ps.radix, &L)) {

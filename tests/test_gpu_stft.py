@@ -460,7 +460,11 @@ def test_enhance_model_framings_round_trip(gpu, sr, n_fft, hop, win):
 
 @pytest.mark.parametrize("n_fft,hop,win", [(1920, 480, 960), (640, 160, 320), (480, 120, 480), (960, 240, 960),
                                            (882, 441, 882), (1200, 300, 1200), (1536, 192, 1536), (1764, 500, 1764),
-                                           (960, 480, 960), (480, 77, 300)])
+                                           (960, 480, 960), (480, 77, 300),
+                                           # the small sizes with a compiled forward plan: inverse-only per-wave plans
+                                           (512, 128, 512), (400, 100, 400), (256, 64, 256), (800, 200, 800),
+                                           (400, 160, 400), (512, 200, 400), (1024, 384, 1024), (2048, 768, 2048),
+                                           (1024, 128, 600)])
 def test_fused_per_wave_inverse_equals_the_two_kernel_form(gpu, n_fft, hop, win):
     """istft on the per-wave transform's compiled-in plans keeps the overlap in an LDS ring; the
     same plan with option wave_istft_fused = 0 writes the frame workspace and runs the
