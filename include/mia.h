@@ -101,7 +101,11 @@ int mia_plan_destroy(mia_plan* plan);
  * projects onto the mel bank with v_mfma_f32_16x16x4_f32 over 16-filter bands instead of
  * sweeping; slower, kept for A/B measurements; needs n_mels <= 128), "w400_dpp_pass2" (1: the
  * LDS-DMA kernel runs the radix-16 pass of its transform across the lanes with DPP operands
- * instead of exchanging through LDS; slower, kept for A/B measurements).  Info keys: "w400_bank"
+ * instead of exchanging through LDS; slower, kept for A/B measurements), "fwd_lane" (1: frame-
+ * major mel rows at n_fft 1024 from the kernel with four frames per wave), "wave_fft" (0: an
+ * n_fft served by the one-wave-per-frame transform back on the whole-row engine),
+ * "wave_istft_fused" (0: a framing whose inverse runs on the one-wave-per-frame transform's
+ * fused kernel back on inverse transform + frame workspace + overlap-add).  Info keys: "w400_bank"
  * (80 / 128 when the compiled sweep applies, else 0), "w400_tables" (1 when the n_fft = 400
  * kernel serves the plan), "w400_mfma_tables" (1 when the matrix-core mode is available),
  * "compute_units".  Not thread-safe against launches that use the plan. */
@@ -156,7 +160,9 @@ int mia_overlap_add(const float* frames, const float* window, int64_t B, int64_t
  * `workspace` must hold mia_istft_workspace_bytes() bytes of device memory.  For
  * hop = n_fft / 4 with n_fft in {1024, 2048, 4096} both steps run in one launch that
  * keeps the overlapping frames in LDS (same result bit for bit) and the workspace
- * size is 0. */
+ * size is 0; so they do (same overlap-add arithmetic, transforms equal to float32 round-off)
+ * for n_fft in {256, 320 .. 2048 with a compiled-in one-wave-per-frame plan} at any hop of at
+ * least n_fft / 8.  Always size the workspace with mia_istft_workspace_bytes(). */
 size_t mia_istft_workspace_bytes(const mia_plan* plan, int64_t B, int64_t F);
 int mia_istft(const mia_plan* plan, const void* spec, int64_t B, int64_t F,
               int64_t stride_b, int64_t stride_bin, int64_t stride_frame,
