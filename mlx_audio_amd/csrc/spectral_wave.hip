@@ -139,6 +139,10 @@ using Plan441 = FixedPlan<441, 64, true, 7, 7, 3, 3>;  // n_fft 882: 20 ms at 44
 using Plan882 = FixedPlan<882, 64, true, 7, 7, 6, 3, 2>;  // n_fft 1764: 40 ms at 44.1 kHz (0.45 -> 0.34 ms with the budget of two waves)
 using Plan600 = FixedPlan<600, 64, true, 12, 10, 5>;   // n_fft 1200: 25 ms at 48 kHz
 using Plan768 = FixedPlan<768, 64, true, 16, 12, 4>;   // n_fft 1536: 32 ms at 48 kHz
+using Plan500 = FixedPlan<500, 64, true, 10, 10, 5>;   // n_fft 1000
+using Plan640 = FixedPlan<640, 64, true, 16, 10, 4>;   // n_fft 1280: 80 ms at 16 kHz
+using Plan800 = FixedPlan<800, 64, true, 16, 10, 5, 1, 2>;  // n_fft 1600: 100 ms at 16 kHz
+using Plan1000 = FixedPlan<1000, 64, true, 10, 10, 10, 1, 2>;  // n_fft 2000
 using Plan160 = FixedPlan<160, 16, true, 16, 10>;      // n_fft 320: 20 ms at 16 kHz, four frames side by side in a wave
 using Plan441u = FixedPlan<441, 64, false, 7, 7, 3, 3>;  // n_fft 441 (odd: unpacked): 10 ms at 44.1 kHz
 // The small sizes with a compiled multi-wave forward plan have no fused inverse of their own
@@ -154,7 +158,8 @@ using Inv512w = FixedPlan<512, 64, true, 8, 8, 8>;           // n_fft 1024
 using Inv1024w = FixedPlan<1024, 64, true, 16, 16, 4, 1, 2>;  // n_fft 2048
 #define MIA_WAVE_INVERSE_ONLY_PLANS(X) X(Inv128) X(Inv200) X(Inv256w) X(Inv400w) X(Inv512w) X(Inv1024w)
 #define MIA_WAVE_FIXED_PLANS(X) \
-  X(Plan960) X(Plan320) X(Plan480) X(Plan240) X(Plan441) X(Plan882) X(Plan600) X(Plan768) X(Plan160) X(Plan441u)
+  X(Plan960) X(Plan320) X(Plan480) X(Plan240) X(Plan441) X(Plan882) X(Plan600) X(Plan768) X(Plan500) X(Plan640) \
+  X(Plan800) X(Plan1000) X(Plan160) X(Plan441u)
 
 // One pass of a compiled-in plan IN PLACE: a lane first reads the points of all its butterflies
 // (ceil(M / R / L) of them, L lanes per frame), then writes their results to the natural-order slots of the same

@@ -351,7 +351,7 @@ def test_any_length_plans_reject_the_entry_points_without_workspace(gpu):
     assert float(out.abs().max()) == 0.0
 
 
-WAVE_SIZES = [4, 6, 24, 98, 300, 320, 480, 640, 882, 960, 1200, 1536, 1764, 1920, 2000, 2016, 2048 - 2 * 7,
+WAVE_SIZES = [4, 6, 24, 98, 300, 320, 480, 640, 882, 960, 1000, 1200, 1280, 1536, 1600, 1764, 1920, 2000, 2016, 2048 - 2 * 7,
               3, 9, 105, 441, 675, 945,   # ... odd sizes, transformed unpacked
               8, 16, 32, 64, 128, 12, 18, 50]  # ... and short ones: several frames side by side in a wave
 

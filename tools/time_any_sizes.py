@@ -12,7 +12,7 @@ def timed(fn, n=5):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n
 y = 0.1 * torch.randn((64, 16000 * 30), device="cuda")
-for n_fft in (320, 441, 480, 640, 882, 960, 1200, 1536, 1764, 1024):
+for n_fft in (320, 441, 480, 640, 882, 960, 1000, 1200, 1280, 1536, 1600, 1764, 2000, 1024):
     hop = n_fft // 4
     a = timed(lambda: melspectrogram(y, sr=16000, n_fft=n_fft, hop_length=hop, n_mels=80))
     b = timed(lambda: stft(y, n_fft=n_fft, hop_length=hop))
