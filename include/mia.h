@@ -108,7 +108,9 @@ int mia_plan_destroy(mia_plan* plan);
  * fused kernel back on inverse transform + frame workspace + overlap-add).  Info keys: "w400_bank"
  * (80 / 128 when the compiled sweep applies, else 0), "w400_tables" (1 when the n_fft = 400
  * kernel serves the plan), "w400_mfma_tables" (1 when the matrix-core mode is available),
- * "compute_units".  Not thread-safe against launches that use the plan. */
+ * "compute_units", "wave_fixed_plan" (1 when a compiled-in plan of the one-wave-per-frame transform
+ * serves the plan's n_fft, 0 for its run-time form, -1 for any other plan), "istft_fused" (1 when
+ * mia_istft runs in one launch without workspace).  Not thread-safe against launches that use the plan. */
 int mia_plan_set_option(mia_plan* plan, const char* key, int value);
 int mia_plan_get_info(const mia_plan* plan, const char* key);
 /* 1 + (T + 2*pad - n_fft) / hop, or a negative error if the signal is too short

@@ -589,12 +589,15 @@ int mia_plan_set_option(mia_plan* plan, const char* key, int value) {
   return MIA_ERR_INVALID;
 }
 
+static bool plan_istft_fused(const mia_plan* plan);
 int mia_plan_get_info(const mia_plan* plan, const char* key) {
   if (plan == nullptr || key == nullptr) return MIA_ERR_INVALID;
   if (strcmp(key, "w400_bank") == 0) return plan->w400_bank;
   if (strcmp(key, "w400_tables") == 0) return plan->d_sweep_meta != nullptr;
   if (strcmp(key, "w400_mfma_tables") == 0) return plan->d_mfma_a != nullptr;
   if (strcmp(key, "compute_units") == 0) return plan->cus;
+  if (strcmp(key, "wave_fixed_plan") == 0) return plan->wave_fft ? forward_wave_fixed_plan(plan->n_fft) : -1;
+  if (strcmp(key, "istft_fused") == 0) return plan_istft_fused(plan) ? 1 : 0;
   set_error("unknown plan info '%s'", key);
   return MIA_ERR_INVALID;
 }

@@ -212,6 +212,7 @@ int launch_inverse(const mia_plan* plan, const InvParams& p, hipStream_t s);
 bool istft_fused_supported(int n_fft, int hop);
 int launch_istft_fused(const mia_plan* plan, const InvParams& p, hipStream_t s);
 bool istft_wave_fused_supported(int n_fft, int hop);
+int forward_wave_fixed_plan(int n_fft);
 int launch_istft_wave_fused(const mia_plan* plan, const InvParams& p, hipStream_t s);
 int launch_init_keys(int* max_keys, int* min_keys, long long n, hipStream_t s);
 int launch_logmel400(const FwdParams& p, const W400Tables& tb, hipStream_t s);

@@ -784,6 +784,16 @@ static int wave_buffers(const wavefft::Passes& ps, int M, int L, int packed) {
   return nbuf;
 }
 
+// Does a compiled-in plan serve this n_fft (1), or the run-time form (0)?  -1: not a per-wave size.
+int forward_wave_fixed_plan(int n_fft) {
+  using namespace wavefft;
+  Passes ps{};
+  int L = 64;
+  if (!forward_wave_plan(n_fft, &ps.n, ps.radix, &L)) return -1;
+  const int packed = n_fft % 2 == 0 ? 1 : 0;
+  return wave_buffers(ps, packed ? n_fft / 2 : n_fft, L, packed) == 1 ? 1 : 0;
+}
+
 // Frame-major rows leave through the FFT buffers: a tile's n_mels x frames values must fit them
 // (true for every long transform; short ones, which put many frames into a tile, only with few bands).
 bool forward_wave_frame_major_ok(int n_fft, int n_mels) {

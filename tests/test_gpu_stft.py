@@ -549,3 +549,30 @@ def test_fused_per_wave_inverse_random_framings(gpu):
         ok = env > 1e-2
         assert ok.mean() > 0.5
         assert np.abs(got - want)[:, ok].max() <= 2e-4, (case, n_fft, hop, win, rows, T, center)
+
+
+def test_compiled_in_plans_are_the_ones_taken(gpu):
+    """The launcher takes a compiled-in plan only when the planner's choice for the n_fft is
+    exactly that plan: a change of the planner's cost model must not silently send these sizes
+    back to the run-time form.  And the framings documented as workspace-free are."""
+    from mlx_audio_amd import _lib
+    from mlx_audio_amd._runtime import get_plan
+    from mlx_audio_amd.primitives.windows import padded_window_np
+
+    lib = _lib.lib()
+    dev = torch.device(gpu)
+
+    def plan(n_fft, hop):
+        return get_plan(dev, n_fft, hop, True, "constant", padded_window_np("hann", n_fft, n_fft))
+
+    for n_fft in (320, 441, 480, 640, 882, 960, 1000, 1200, 1280, 1536, 1600, 1764, 1920, 2000):
+        assert lib.mia_plan_get_info(plan(n_fft, n_fft // 4).handle, b"wave_fixed_plan") == 1, n_fft
+    for n_fft in (300, 2016, 98):
+        assert lib.mia_plan_get_info(plan(n_fft, n_fft // 2).handle, b"wave_fixed_plan") == 0, n_fft
+    assert lib.mia_plan_get_info(plan(1024, 256).handle, b"wave_fixed_plan") == -1
+    fused = [(1024, 256), (2048, 512), (4096, 1024), (1920, 480), (640, 160), (480, 120), (960, 300),
+             (256, 64), (400, 160), (512, 128), (800, 200), (1024, 384), (2048, 768), (1764, 441)]
+    for n_fft, hop in fused:
+        assert lib.mia_plan_get_info(plan(n_fft, hop).handle, b"istft_fused") == 1, (n_fft, hop)
+    for n_fft, hop in ((320, 80), (441, 110), (4096, 512), (300, 75), (1920, 100)):
+        assert lib.mia_plan_get_info(plan(n_fft, hop).handle, b"istft_fused") == 0, (n_fft, hop)
