@@ -457,6 +457,21 @@ int mia_gate_mask_box_spec(const void* spec, const float* thr, int64_t rows, int
                            int64_t rows_thr, float gain, int keep, float p, int size_freq, float* out,
                            void* stream);
 
+/* The stationary gate's mask pipeline and its inverse STFT in one launch (spectral_gate.py:
+ * 124-238 from the soft mask to the waveform): spec is the UN-gated STFT, complex64 (B, F, bins)
+ * rows as mia_stft writes them, thr (rows_thr, bins) with rows_thr = B or 1, and every bin enters
+ * the inverse transform scaled by m' where m = clip((|z| - thr * gain) / (|z| + 1e-8), 0, 1) is
+ * averaged over size_freq bins, then over size_freq2 bins, then over size_time frames (each a
+ * mia_box_filter: ends repeated, 1 = none) and m' = keep ? 1 - p (1 - m) : m.  Neither the mask
+ * nor the gated spectrum is written anywhere; the result equals mia_gate_mask_box_spec +
+ * mia_gate_apply_spectrum + mia_istft to float32 rounding.  Plans of 1024 and 2048 points at
+ * hop n_fft / 4, windows of up to 33 / 4 bins and 8 frames (mia_istft_gated_supported says so;
+ * MIA_ERR_UNSUPPORTED otherwise).  out (B, out_len) as mia_istft's, no workspace. */
+int mia_istft_gated_supported(const mia_plan* plan, int size_freq, int size_freq2, int size_time);
+int mia_istft_gated(const mia_plan* plan, const void* spec, int64_t B, int64_t F, int64_t out_len,
+                    float scale, const float* thr, int64_t rows_thr, float gain, int keep, float p,
+                    int size_freq, int size_freq2, int size_time, float* out, void* stream);
+
 /* ---- HTDemucs input normalisation (models/demucs/model.py:206-233) ---------------------
  * mia_normalize_rows: per row of n floats, mean and population standard deviation, then
  *   out = (x - mean) / (std + eps) (the time branch, model.py:231-233, a batch item's channels

@@ -846,6 +846,59 @@ int mia_istft(const mia_plan* plan, const void* spec, int64_t B, int64_t F, int6
                          out, stream);
 }
 
+int mia_istft_gated_supported(const mia_plan* plan, int size_freq, int size_freq2, int size_time) {
+  return plan && !plan->generic && !plan->wave_fft &&
+                 mia::istft_gated_supported(plan->n_fft, plan->hop, size_freq, size_freq2, size_time)
+             ? 1 : 0;
+}
+
+int mia_istft_gated(const mia_plan* plan, const void* spec, int64_t B, int64_t F, int64_t out_len,
+                    float scale, const float* thr, int64_t rows_thr, float gain, int keep,
+                    float prop_decrease, int size_freq, int size_freq2, int size_time, float* out,
+                    void* stream) {
+  MIA_REQUIRE(plan != nullptr, "null plan");
+  MIA_REQUIRE(B >= 0 && F >= 0 && out_len >= 0, "negative shape");
+  MIA_REQUIRE(F < (1LL << 31), "too many frames per row: %lld", (long long)F);
+  MIA_REQUIRE(rows_thr == 1 || rows_thr == B, "thresholds for %lld rows, the spectrum has %lld",
+              (long long)rows_thr, (long long)B);
+  if (!mia_istft_gated_supported(plan, size_freq, size_freq2, size_time)) {
+    set_error("no gated inverse for n_fft=%d hop=%d and windows of %d / %d bins, %d frames",
+              plan->n_fft, plan->hop, size_freq, size_freq2, size_time);
+    return MIA_ERR_UNSUPPORTED;
+  }
+  MIA_REQUIRE((spec && out && thr) || B == 0 || F == 0 || out_len == 0, "null buffer");
+  if (B == 0 || out_len == 0) return MIA_OK;
+  if (F == 0) {
+    MIA_CHECK_HIP(hipMemsetAsync(out, 0, sizeof(float) * (size_t)B * (size_t)out_len,
+                                 (hipStream_t)stream));
+    return MIA_OK;
+  }
+  const long long bins = plan->n_fft / 2 + 1;
+  InvParams p{};
+  p.spec = reinterpret_cast<const float2*>(spec);
+  p.B = B;
+  p.F = F;
+  p.sb = F * bins;
+  p.sk = 1;
+  p.sf = bins;
+  p.tw = plan->d_tw;
+  p.win = plan->d_window;
+  p.hop = plan->hop;
+  p.out_len = out_len;
+  p.scale = scale;
+  p.out = out;
+  GateParams g{};
+  g.thr = thr;
+  g.thr_stride = rows_thr == 1 ? 0 : bins;
+  g.gain = gain;
+  g.prop = prop_decrease;
+  g.keep = keep ? 1 : 0;
+  g.s1 = size_freq;
+  g.s2 = size_freq2;
+  g.st = size_time;
+  return launch_istft_gated(plan, p, g, (hipStream_t)stream);
+}
+
 }  // extern "C"
 
 extern "C" size_t mia_mel_workspace_bytes(const mia_plan* plan, int64_t B, int64_t T) {

@@ -10,20 +10,6 @@
 
 namespace mia {
 
-constexpr float kGateEps = 1e-8f;  // the reference's DIVISION_EPSILON
-
-// Mean of a window from its double-precision sum: one multiplication by the reciprocal a thread
-// takes once, in every kernel alike (the fused forms stay bit-identical to the separate ones).
-__device__ __forceinline__ double window_inv(int size) { return 1.0 / (double)size; }
-__device__ __forceinline__ float window_mean(double sum, double inv) { return (float)(sum * inv); }
-
-// The soft mask value clip((m - t * gain) / (m + eps), 0, 1), with the product and the difference
-// as one fused multiply-add spelled out: left to the compiler, the contraction differs between
-// kernels and the fused forms would not be bit-identical to the separate launches.
-__device__ __forceinline__ float gate_mask_value(float m, float t, float gain) {
-  return fminf(fmaxf(__builtin_fmaf(-t, gain, m) / (m + kGateEps), 0.0f), 1.0f);
-}
-
 // energy[row, f] = mean over bins of mag^2.  A block takes 32 frames; eight groups of threads
 // each sum every eighth bin (one thread per frame could keep only a few hundred waves in
 // flight, each behind a chain of `bins` loads), and the eight partial sums are added in a fixed

@@ -133,6 +133,19 @@ __device__ __forceinline__ bool xcd_tile(unsigned gx, unsigned gy, unsigned& tx,
   return true;
 }
 
+// Arithmetic of the spectral gate shared by its kernels (so that a fused form gives the bits of
+// the separate launches).  Mean of a window from its double-precision sum: one multiplication
+// by the reciprocal a thread takes once.
+constexpr float kGateEps = 1e-8f;  // the reference's DIVISION_EPSILON
+__device__ __forceinline__ double window_inv(int size) { return 1.0 / (double)size; }
+__device__ __forceinline__ float window_mean(double sum, double inv) { return (float)(sum * inv); }
+// The soft mask value clip((m - t * gain) / (m + eps), 0, 1), with the product and the difference
+// as one fused multiply-add spelled out: left to the compiler, the contraction differs between
+// kernels.
+__device__ __forceinline__ float gate_mask_value(float m, float t, float gain) {
+  return fminf(fmaxf(__builtin_fmaf(-t, gain, m) / (m + kGateEps), 0.0f), 1.0f);
+}
+
 struct FwdParams {
   const float* y;
   long long B, T, F;
@@ -207,7 +220,18 @@ struct InvParams {
   float* out;            // (B, out_len)
 };
 
+// The gate applied to the spectrum on its way into the fused inverse STFT.
+struct GateParams {
+  const float* thr;      // (rows_thr, bins) thresholds
+  long long thr_stride;  // bins, or 0: one row of thresholds for every batch row
+  float gain, prop;
+  int keep;              // m -> 1 - prop (1 - m) after the averages
+  int s1, s2, st;        // windows: first and second average over bins, then over frames (1: none)
+};
+
 int launch_forward(const mia_plan* plan, const FwdParams& p, int mode, hipStream_t s);
+bool istft_gated_supported(int n_fft, int hop, int s1, int s2, int st);
+int launch_istft_gated(const mia_plan* plan, const InvParams& p, const GateParams& g, hipStream_t s);
 int launch_inverse(const mia_plan* plan, const InvParams& p, hipStream_t s);
 bool istft_fused_supported(int n_fft, int hop);
 int launch_istft_fused(const mia_plan* plan, const InvParams& p, hipStream_t s);

@@ -191,14 +191,18 @@ struct FrameTwiddles {
 // exit the bins of the frame at `xs_next` (fetched behind the last pass's LDS reads, so
 // that their latency hides behind the last butterflies and the stores).
 // `rt`: the thread's twiddles in registers, or nullptr (then they come from the table `tw`).
-template <class C, bool TO_BUF, bool RT, class Sink>
+// `gain(k)`: a real factor for bin k, applied as the bins enter the split step (NoGain: none).
+struct NoGain {};
+template <class C, bool TO_BUF, bool RT, class Sink, class Gain = NoGain>
 __device__ __forceinline__ void inverse_frame(const InvParams& p, const float2* __restrict__ tw,
                                               float2* __restrict__ buf,
                                               const float2* __restrict__ xs, bool valid, int t,
                                               FrameBins<C>& fb, const float2* __restrict__ xs_next,
                                               bool valid_next, Sink sink,
-                                              const FrameTwiddles<C>* rt = nullptr) {
+                                              const FrameTwiddles<C>* rt = nullptr,
+                                              Gain gain = Gain{}) {
   constexpr int M = C::M, T = C::T;
+  constexpr bool GATED = !std::is_same<Gain, NoGain>::value;
   const bool t0 = (t == 0);
   const float inv_m = 1.0f / float(M);
   if (!fb.ready) fetch_bins<C>(fb, p, xs, valid, t);
@@ -213,6 +217,11 @@ __device__ __forceinline__ void inverse_frame(const InvParams& p, const float2* 
       const T0Slot ts = t0_slot<R>(s);
       const int k = t0 ? ts.k_half * (S0 / 2) : t + S0 * s;
       float2 xk = fb.xk[s], xm = fb.xm[s];
+      if constexpr (GATED) {
+        const float gk = gain(k), gm = gain(M - k);
+        xk = {xk.x * gk, xk.y * gk};
+        xm = {xm.x * gm, xm.y * gm};
+      }
       if (k == 0) {  // the real transform ignores Im X[0] and Im X[M]
         xk.y = 0.0f;
         xm.y = 0.0f;
@@ -230,7 +239,13 @@ __device__ __forceinline__ void inverse_frame(const InvParams& p, const float2* 
     }
     // The bins are consumed: the next frame's are fetched here, so that their way from memory
     // is covered by the remaining passes (behind the last pass there is too little left).
-    const float2 xh_cur = fb.xh;
+    float2 xh_cur = fb.xh;
+    if constexpr (GATED) {
+      if (t0) {
+        const float gh = gain(M / 2);
+        xh_cur = {xh_cur.x * gh, xh_cur.y * gh};
+      }
+    }
     fb.ready = xs_next != nullptr;
     if (fb.ready) fetch_bins<C>(fb, p, xs_next, valid_next, t);
     float2 A[R], Bv[R];
@@ -570,6 +585,304 @@ __global__ __launch_bounds__(C::T) void istft_own_kernel(InvParams p) {
   }
 }
 
+// istft_own_kernel for the spectral gate: the spectrum it reads is the un-gated STFT, (B, F,
+// bins) with contiguous rows of bins, and every bin is scaled on its way into the split step by
+// the gate's mask - soft mask from |z| and a per-bin threshold, averaged over s1 and then s2
+// bins and then over st frames, then the keep step - so neither the mask nor the gated spectrum
+// ever exists in memory.  The workgroup keeps the st rows of twice-averaged mask values that the
+// frame it is about to transform needs in an LDS ring (row of frame f in slot f mod st) and makes
+// the next row just before it is needed: mask values of one frame into the (idle) transform
+// buffer, windows summed from there.  Indices beyond the ends repeat the end value in both
+// directions, every mean is its window's double-precision sum times 1 / size rounded to float32,
+// in the order the separate kernels of the gate take them.  A run that starts inside a row makes
+// the rows its warm-up frames need first.  Element i of a row sits at i + i / 8, so that threads
+// on runs of eight bins and threads on consecutive bins both spread over the banks.
+constexpr int kGateMaxS1 = 16, kGateMaxS2 = 4, kGateMaxSt = 8;
+constexpr int kGateNO = 9 + kGateMaxS2 - 1;        // first averages a thread makes at most
+constexpr int kGateNW = kGateNO + kGateMaxS1 - 1;  // mask values it reads for them at most
+__host__ __device__ constexpr int gate_pos(int i) { return i + (i >> 3); }
+// (the ring's rows are plain: a padded row would cost the 2048-point kernel a workgroup per CU)
+template <int M>
+constexpr int gate_row_stride() { return M + 4; }
+
+// |z| of a spectrum value (no scaling against overflow: an STFT of float32 audio is far from it)
+__device__ __forceinline__ float gate_abs(float2 z) {
+#ifdef MIA_GATE_HYPOT
+  return hypotf(z.x, z.y);
+#else
+  return sqrtf(__builtin_fmaf(z.x, z.x, z.y * z.y));
+#endif
+}
+
+// m1[i] = mean of w[i .. i + S1 - 1], i < kGateNO: the window's double-precision sum in
+// ascending order times 1 / S1, as box_filter_kernel takes it.
+template <int S1>
+__device__ __forceinline__ void gate_window_means(const float (&w)[kGateNW], float (&m1)[kGateNO], double inv) {
+#pragma unroll
+  for (int i = 0; i < kGateNO; ++i) {
+    double sum = 0.0;
+#pragma unroll
+    for (int j = 0; j < S1; ++j) sum += (double)w[i + j];
+    m1[i] = S1 == 1 ? (float)sum : window_mean(sum, inv);
+  }
+}
+
+template <class C, int FT>
+__global__ __launch_bounds__(C::T, 2) void istft_gate_kernel(InvParams p, GateParams g) {
+  constexpr int N = C::N, M = N / 2, HOP = N / 4, WG = C::T;
+  constexpr int NC = M / WG;
+  constexpr int SPAN = FT * HOP;
+  constexpr int RING = SPAN + N;
+  constexpr int HC = HOP / (2 * WG);
+  constexpr int RS = gate_row_stride<M>();
+  static_assert(HOP % (2 * WG) == 0 && HC >= 1, "hop must be a multiple of twice the workgroup size");
+  static_assert(FT >= 3, "one warm-up tile must cover the three frames that reach into a run");
+  static_assert((M / C::RL) % WG == 0 && (WG % 64) == 0, "a frame is the whole workgroup");
+  static_assert(M == 8 * WG, "a thread makes the mask values of eight bins");
+  static_assert(gate_pos(M + kGateNW + 2) + 1 <= 2 * C::LBUF, "a frame's mask values must fit the transform buffer");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float2* buf = reinterpret_cast<float2*>(smem_raw);
+  float2* acc = buf + C::LBUF;  // RING / 2 sample pairs
+  float* ring = reinterpret_cast<float*>(acc) + RING;  // g.st rows of RS mask values
+  float* tmp0 = reinterpret_cast<float*>(buf);
+
+  const int t = threadIdx.x;
+  const float2* __restrict__ tw = p.tw;
+  const float2* __restrict__ win2 = reinterpret_cast<const float2*>(p.win);
+
+  const long long total = p.B * p.tiles;
+  const long long first = (long long)blockIdx.x * p.tiles_per_wg;
+  const long long last = first + p.tiles_per_wg < total ? first + p.tiles_per_wg : total;
+  if (first >= last) return;
+
+  float2 wreg[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) wreg[c] = win2[t + c * WG];
+  float2 wsq[HC];
+#pragma unroll
+  for (int m = 0; m < HC; ++m) {
+    float2 ws = {0.0f, 0.0f};
+#pragma unroll
+    for (int c = 3; c >= 0; --c) {
+      const float2 w = wreg[m + c * HC];
+      ws = {fmaf(w.x, w.x, ws.x), fmaf(w.y, w.y, ws.y)};
+    }
+    wsq[m] = ws;
+  }
+
+  long long idx = (first % p.tiles) > 0 ? first - 1 : first;
+  for (int q = t; q < RING / 2; q += WG) acc[q] = {0.0f, 0.0f};
+  int origin = 0;
+  auto slot = [&](int q) {
+    const int s2 = origin + q;
+    return s2 >= RING / 2 ? s2 - RING / 2 : s2;
+  };
+  __syncthreads();
+
+  // ---- the mask rows ---------------------------------------------------------------------
+  const int s1 = g.s1, s2w = g.s2, st = g.st;
+  const int h1 = s1 / 2, h2 = s2w / 2;
+  const int back = st / 2, ahead = (st - 1) / 2;  // frames of the time window before / after its own
+  const int nF = (int)p.F;
+  const int last_slot = (nF - 1) % st;
+  const double inv1 = window_inv(s1), inv2 = window_inv(s2w), invt = window_inv(st);
+  // A row's spectrum values are fetched a row ahead (they arrive behind a transform): mz holds
+  // bins t + i WG of frame pf_f of row pf_b, mzM bin M (last thread).
+  float2 mz[8], mzM = {0.0f, 0.0f};
+  long long pf_b = -1;
+  int pf_f = -1;
+  auto fetch_row = [&](long long b, int fr) {
+    const float2* __restrict__ zr = p.spec + b * p.sb + (long long)fr * p.sf;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) mz[i] = zr[t + i * WG];
+    if (t == WG - 1) mzM = zr[M];
+    pf_b = b;
+    pf_f = fr;
+  };
+  // tmp0[gate_pos(kGateMaxS2 / 2 + h1 + k)] = mask value of bin k, the ends repeated h1 and
+  // (s1 - 1) / 2 times; the window of the first average at bin e starts at kGateMaxS2 / 2 + e.
+  constexpr int SH = kGateMaxS2 / 2;
+  auto mask_row = [&](long long b, int fr) {
+    if (pf_b != b || pf_f != fr) fetch_row(b, fr);
+    const float* __restrict__ th = g.thr + b * g.thr_stride;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int k = t + i * WG;
+      const float v = gate_mask_value(gate_abs(mz[i]), th[k], g.gain);
+      tmp0[gate_pos(SH + h1 + k)] = v;
+      if (k == 0) {
+        for (int j = 0; j < h1; ++j) tmp0[gate_pos(SH + j)] = v;
+      }
+    }
+    if (t == WG - 1) {
+      const float v = gate_mask_value(gate_abs(mzM), th[M], g.gain);
+      for (int j = 0; j <= (s1 - 1) / 2; ++j) tmp0[gate_pos(SH + h1 + M + j)] = v;
+    }
+    if (fr + 1 < nF) fetch_row(b, fr + 1);
+    __syncthreads();
+    // thread t: bins 8 t .. 8 t + 7 (the last thread also bin M).  Its first averages are those
+    // at bins e0 + i, e0 = 8 t - s2 / 2; beyond the ends they repeat the end's.
+    const int e0 = 8 * t - h2;
+    float w[kGateNW], m1[kGateNO];
+#pragma unroll
+    for (int x = 0; x < kGateNW; ++x) w[x] = tmp0[gate_pos(SH + e0 + x)];
+    switch (s1) {
+#define MIA_GATE_S1(S) case S: gate_window_means<S>(w, m1, inv1); break;
+      MIA_GATE_S1(1) MIA_GATE_S1(2) MIA_GATE_S1(3) MIA_GATE_S1(4) MIA_GATE_S1(5) MIA_GATE_S1(6)
+      MIA_GATE_S1(7) MIA_GATE_S1(8) MIA_GATE_S1(9) MIA_GATE_S1(10) MIA_GATE_S1(11) MIA_GATE_S1(12)
+      MIA_GATE_S1(13) MIA_GATE_S1(14) MIA_GATE_S1(15)
+#undef MIA_GATE_S1
+      default: gate_window_means<16>(w, m1, inv1); break;
+    }
+    if (t == 0) {  // bins below 0: the average at bin 0, which is m1[h2]
+      const float at0 = h2 == 2 ? m1[2] : (h2 == 1 ? m1[1] : m1[0]);
+      if (h2 >= 1) m1[0] = at0;
+      if (h2 >= 2) m1[1] = at0;
+    }
+    if (t == WG - 1) {  // bins above M: the average at bin M, which is m1[8 + h2]
+      const float atM = h2 == 2 ? m1[10] : (h2 == 1 ? m1[9] : m1[8]);
+#pragma unroll
+      for (int i = 9; i < kGateNO; ++i) {
+        if (i > 8 + h2) m1[i] = atM;
+      }
+    }
+    float* __restrict__ row = ring + (fr % st) * RS;
+#pragma unroll
+    for (int o = 0; o < 9; ++o) {
+      double sb = 0.0;
+#pragma unroll
+      for (int q = 0; q < kGateMaxS2; ++q) {
+        if (q < s2w) sb += (double)m1[o + q];
+      }
+      const float m2 = s2w == 1 ? (float)sb : window_mean(sb, inv2);
+      if (o < 8 || t == WG - 1) row[8 * t + o] = m2;
+    }
+    __syncthreads();
+  };
+  long long mb = -1;  // row whose mask rows the ring holds
+  int mhi = -1;       // ... the last frame made
+
+  FrameTwiddles<C> rt;
+  rt.load(tw, t);
+  FrameBins<C> fb;
+  fb.ready = false;
+  for (; idx < last; ++idx) {
+    const long long b = idx / p.tiles;
+    const int tile = (int)(idx - b * p.tiles);
+    const long long f0 = (long long)tile * FT;
+    const int nf = p.F - f0 < FT ? (int)(p.F - f0) : FT;
+    const float2* __restrict__ xrow = p.spec + b * p.sb;
+#pragma unroll 1
+    for (int it = 0; it < FT; ++it) {
+      const bool valid = it < nf;
+      const int f = (int)f0 + it;
+      if (valid) {
+        if (b != mb) {
+          mb = b;
+          mhi = (f - back > 0 ? f - back : 0) - 1;
+        }
+        const int need = f + ahead < nF - 1 ? f + ahead : nF - 1;
+        while (mhi < need) mask_row(b, ++mhi);
+      }
+      int off[kGateMaxSt];  // ring rows of the frames f - back .. f + ahead, ends repeated
+      {
+        int sl = (f - back + st) % st;  // (back < st)
+#pragma unroll
+        for (int q = 0; q < kGateMaxSt; ++q) {
+          const int fq = f - back + q;
+          off[q] = (fq < 0 ? 0 : (fq > nF - 1 ? last_slot : sl)) * RS;
+          sl = sl + 1 == st ? 0 : sl + 1;
+        }
+      }
+      auto gain_of = [&](int k) {
+        double sum = 0.0;
+#pragma unroll
+        for (int q = 0; q < kGateMaxSt; ++q) {
+          if (q < st) sum += (double)ring[off[q] + k];
+        }
+        float m = st == 1 ? (float)sum : window_mean(sum, invt);
+        if (g.keep) m = 1.0f - g.prop * (1.0f - m);
+        return m;
+      };
+      const float2* __restrict__ xs = xrow + (valid ? f : 0) * p.sf;
+      const float2* xs_next = nullptr;
+      bool valid_next = false;
+      if (it + 1 < FT) {
+        valid_next = it + 1 < nf;
+        xs_next = xrow + (valid_next ? f + 1 : 0) * p.sf;
+      } else if (idx + 1 < last) {
+        const long long bn = (idx + 1) / p.tiles;
+        const long long fn = ((idx + 1) - bn * p.tiles) * FT;
+        valid_next = true;
+        xs_next = p.spec + bn * p.sb + fn * p.sf;
+      }
+      const int qf = it * (HOP / 2) + t;
+      inverse_frame<C, false, true>(
+          p, tw, buf, xs, valid, t, fb, xs_next, valid_next,
+          [&](int, float2 v, int c) {
+            if (valid) {
+              const int a = slot(qf + c * WG);
+              const float2 sum = acc[a];
+              acc[a] = {fmaf(wreg[c].x, v.x, sum.x), fmaf(wreg[c].y, v.y, sum.y)};
+            }
+          },
+          &rt, gain_of);
+    }
+    const long long base = f0 * HOP;
+    const bool row_end = tile == p.tiles - 1;
+    const long long left = p.out_len - base;
+    float* __restrict__ orow = p.out + b * p.out_len + base;
+    const bool aligned8 = (reinterpret_cast<uintptr_t>(orow) & 7) == 0;
+    if (!row_end && f0 >= 3 && nf == FT && left >= SPAN && aligned8) {
+#pragma unroll
+      for (int k = 0; k < SPAN / (2 * WG); ++k) {
+        const int a = slot(t + k * WG);
+        const float2 sum = acc[a];
+        acc[a] = {0.0f, 0.0f};
+        if (idx >= first) {
+          const float2 ws = wsq[k % HC];
+          reinterpret_cast<float2*>(orow)[t + k * WG] = {sum.x / fmaxf(ws.x, 1e-8f) * p.scale,
+                                                         sum.y / fmaxf(ws.y, 1e-8f) * p.scale};
+        }
+      }
+    } else {
+      __syncthreads();
+      float* __restrict__ accf = reinterpret_cast<float*>(acc);
+      const int avail = row_end ? RING : SPAN;
+      const int count = left < avail ? (left < 0 ? 0 : (int)left) : avail;
+      for (int q = t; q < avail; q += WG) {
+        int a = 2 * origin + q;
+        a = a >= RING ? a - RING : a;
+        const float sum = accf[a];
+        accf[a] = 0.0f;
+        if (q < count && idx >= first) {
+          int fa = q - N + 1;
+          fa = fa <= 0 ? -((-fa) / HOP) : (fa + HOP - 1) / HOP;
+          if (f0 + fa < 0) fa = (int)-f0;
+          int fbx = q / HOP;
+          if (f0 + fbx > p.F - 1) fbx = (int)(p.F - 1 - f0);
+          float wsum = 0.0f;
+          for (int f = fa; f <= fbx; ++f) {
+            const float w = p.win[q - f * HOP];
+            wsum = fmaf(w, w, wsum);
+          }
+          orow[q] = sum / fmaxf(wsum, 1e-8f) * p.scale;
+        }
+      }
+      if (row_end && idx >= first) {
+        for (long long i = base + RING + t; i < p.out_len; i += WG) p.out[b * p.out_len + i] = 0.0f;
+      }
+      __syncthreads();
+    }
+    if (row_end) {
+      origin = 0;
+      fb.ready = fb.ready && idx + 1 < last;
+    } else {
+      origin = slot(SPAN / 2);
+    }
+  }
+}
+
 //                    N     T   R0  R1  R2  PADQ
 using Inv256 = InvCfg<256, 8, 8, 16, 1, 8>;
 // 400 and 800 points: twenty threads per frame and ten / twenty points per thread in four passes
@@ -651,6 +964,60 @@ static int launch_fused_own(const InvParams& p0, hipStream_t s) {
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WG), lds, s, p);
   MIA_CHECK_HIP(hipGetLastError());
   return MIA_OK;
+}
+
+#ifndef MIA_GATE_FT
+#define MIA_GATE_FT 3  // frames per tile: with 3, four workgroups of the 2048-point kernel fit a CU's LDS
+#endif
+template <class C, int FT>
+static int launch_gated_own(const InvParams& p0, const GateParams& g, hipStream_t s) {
+  constexpr int WG = C::T;
+  InvParams p = p0;
+  p.tiles = (int)((p.F + FT - 1) / FT);
+  const long long total = p.B * p.tiles;
+  if (total <= 0) return MIA_OK;
+  const size_t lds = sizeof(float2) * C::LBUF + sizeof(float) * ((size_t)FT * (C::N / 4) + C::N) +
+                     sizeof(float) * (size_t)g.st * gate_row_stride<C::N / 2>();
+  auto kern = istft_gate_kernel<C, FT>;
+  if (lds > 64 * 1024) {
+    MIA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  }
+  int dev = 0, cus = 256, per_cu = 1;
+  MIA_CHECK_HIP(hipGetDevice(&dev));
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), WG,
+                                                   lds) != hipSuccess || per_cu < 1) {
+    per_cu = 1;
+  }
+  long long grid = (long long)cus * per_cu;
+  if (grid > total) grid = total;
+  const long long per_wg = (total + grid - 1) / grid;
+  if (per_wg > 0x7fffffffLL) {
+    set_error("batch too large for one launch: %lld tiles (split the batch)", total);
+    return MIA_ERR_UNSUPPORTED;
+  }
+  p.tiles_per_wg = (int)per_wg;
+  grid = (total + per_wg - 1) / per_wg;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WG), lds, s, p, g);
+  MIA_CHECK_HIP(hipGetLastError());
+  return MIA_OK;
+}
+
+// The gate inside the inverse: 1024 and 2048 points at hop n_fft / 4, windows the rows in LDS hold.
+bool istft_gated_supported(int n_fft, int hop, int s1, int s2, int st) {
+  return (n_fft == 1024 || n_fft == 2048) && hop * 4 == n_fft && s1 >= 1 && s1 <= kGateMaxS1 &&
+         s2 >= 1 && s2 <= kGateMaxS2 && st >= 1 && st <= kGateMaxSt;
+}
+
+int launch_istft_gated(const mia_plan* plan, const InvParams& p, const GateParams& g, hipStream_t s) {
+  if (!istft_gated_supported(plan->n_fft, p.hop, g.s1, g.s2, g.st)) {
+    set_error("no gated inverse for n_fft=%d hop=%d windows %d / %d / %d", plan->n_fft, p.hop, g.s1,
+              g.s2, g.st);
+    return MIA_ERR_UNSUPPORTED;
+  }
+  return plan->n_fft == 1024 ? launch_gated_own<Inv1024, MIA_GATE_FT>(p, g, s)
+                             : launch_gated_own<Inv2048, MIA_GATE_FT>(p, g, s);
 }
 
 // The framings a fused kernel covers: hop = n_fft / 4 with hop a multiple of 256 on the compiled

@@ -14,8 +14,9 @@ import numpy as np
 import torch
 
 from .. import _lib
-from .._runtime import as_device_f32, stream_ptr
+from .._runtime import as_device_f32, get_plan, stream_ptr
 from .stft import istft, magnitude, stft
+from .windows import padded_window_np
 
 
 def _validate(n_fft, hop_length, prop_decrease) -> None:
@@ -30,6 +31,7 @@ def _validate(n_fft, hop_length, prop_decrease) -> None:
 
 
 _SPEC_MASK_MAX_WINDOW = 33   # bins the spectrum form of the mask kernel averages at most
+_FUSE_INVERSE = True         # tests switch the one-launch gate + inverse STFT off to compare
 
 
 class _Ops:
@@ -168,6 +170,35 @@ class _Ops:
             mask = self.box(mask, size, 1) if axis == "f" else self.box(mask, 1, size)
         return self.apply_spectrum(spec, mask, not keep_first, prop_decrease, last, last_freq)
 
+    @staticmethod
+    def fused_windows(steps):
+        """(size_freq, size_freq2, size_time) when `steps` is at most an average over bins, a
+        second one, and one over frames, in that order - the shape the inverse STFT kernel can
+        apply by itself - else None."""
+        steps = list(steps)
+        first = steps.pop(0)[1] if steps and steps[0][0] == "f" else 1
+        last = steps.pop()[1] if steps and steps[-1][0] == "t" else 1
+        second = steps.pop()[1] if steps and steps[-1][0] == "f" else 1
+        return None if steps else (first, second, last)
+
+    def gated_istft(self, spec, thr, gain, windows, prop_decrease, n_fft, hop_length, win_length,
+                    window, n_samples):
+        """istft(gate(...), center=True, length=n_samples) in one launch, or None when the plan
+        or the windows have no such kernel.  spec: the (rows, bins, frames) view stft() returns."""
+        spec_rows = spec.transpose(1, 2)
+        if not spec_rows.is_contiguous() or thr.dim() != 2:
+            return None
+        plan = get_plan(self.dev, n_fft, hop_length, True, "constant",
+                        padded_window_np(window, win_length, n_fft))
+        if not self.lib.mia_istft_gated_supported(plan.handle, *windows):
+            return None
+        rows, frames, _ = spec_rows.shape
+        out = self.new((rows, n_samples + n_fft))
+        self._run("mia_istft_gated", plan.handle, spec_rows.data_ptr(), rows, frames, out.shape[1],
+                  1.0, thr.data_ptr(), thr.shape[0], float(gain), 1, float(prop_decrease),
+                  int(windows[0]), int(windows[1]), int(windows[2]), out.data_ptr())
+        return out[:, n_fft // 2:n_fft // 2 + n_samples]
+
     def times(self, a, b):
         out = self.new(a.shape)
         self._run("mia_mask_op", a.data_ptr(), b.data_ptr(), a.numel(), 1, 0.0, out.data_ptr())
@@ -233,9 +264,15 @@ def spectral_gate(audio, noise_profile=None, *, sr: int = 22050, n_fft: int = 20
         tc_frames = max(1, int(time_constant_s * sr / hop_length))
         thr = ops.time_min(mag, tc_frames)
 
-    enhanced = ops.gate(mag, C, thr, gain, steps, False, prop_decrease)
-    y = istft(enhanced, hop_length=hop_length, win_length=win_length, window=window, center=True,
-              length=n_samples)
+    y = None
+    windows = ops.fused_windows(steps) if direct and _FUSE_INVERSE else None
+    if windows is not None:   # mask, averages and inverse STFT in one launch
+        y = ops.gated_istft(C, thr, gain, windows, prop_decrease, n_fft, hop_length, win_length,
+                            window, n_samples)
+    if y is None:
+        enhanced = ops.gate(mag, C, thr, gain, steps, False, prop_decrease)
+        y = istft(enhanced, hop_length=hop_length, win_length=win_length, window=window, center=True,
+                  length=n_samples)
     return y[0] if is_1d else y
 
 

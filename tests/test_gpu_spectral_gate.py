@@ -251,6 +251,87 @@ def test_behaviour_and_c_abi_checks(gpu):
     assert lib.mia_gate_apply_spectrum(0, 0, 0, 4, 3, 0, 1.0, 1, 1, 0, s) == _lib.MIA_OK
 
 
+_ONE_LAUNCH_CASES = [
+    {}, {"n_fft": 1024}, {"sr": 16000}, {"sr": 44100, "n_grad_freq": 3, "n_grad_time": 5, "prop_decrease": 0.8},
+    {"n_grad_freq": 1, "n_grad_time": 1}, {"freq_smooth_hz": 0.0, "time_smooth_ms": 0.0},
+    {"n_grad_freq": 4, "n_grad_time": 8, "freq_smooth_hz": 172.0}, {"noise": True},
+    {"window": "hamming", "win_length": 1500, "prop_decrease": 0.5},
+]
+
+
+@pytest.mark.parametrize("shape", [(1, 44100), (3, 30000), (2, 1500), (1, 512), (7, 100000)])
+def test_one_launch_gate_and_inverse_equals_the_separate_launches(gpu, shape):
+    """The stationary gate whose mask pipeline runs inside the inverse STFT kernel (neither mask
+    nor gated spectrum in memory) against the same call on the separate kernels: rows shorter
+    than a tile, rows that end inside a tile, several rows per workgroup, every window shape the
+    kernel takes; equal to float32 rounding of the mask values."""
+    import importlib
+    mod = importlib.import_module("mlx_audio_amd.primitives.spectral_gate")
+    g = torch.Generator(device=gpu)
+    g.manual_seed(shape[0] * 1000 + shape[1])
+    x = 0.05 * torch.randn(shape, generator=g, device=gpu)
+    t = torch.arange(shape[1], device=gpu) / 22050.0
+    x = x + 0.5 * torch.sin(2 * np.pi * 440 * t) * (t > 0.4 * shape[1] / 22050.0)
+    for case in _ONE_LAUNCH_CASES:
+        kw = dict(case)
+        if kw.pop("noise", False):
+            kw["noise_profile"] = 0.05 * torch.randn(8000, generator=g, device=gpu)
+        assert mod._FUSE_INVERSE
+        one = spectral_gate(x, **kw)
+        try:
+            mod._FUSE_INVERSE = False
+            three = spectral_gate(x, **kw)
+        finally:
+            mod._FUSE_INVERSE = True
+        assert one.shape == three.shape == x.shape
+        assert (one - three).abs().max().item() <= 1e-6 * max(three.abs().max().item(), 1e-3), case
+
+
+def test_one_launch_gate_is_the_path_taken(gpu):
+    """The default call's framing and windows have the one-launch kernel, wider windows and other
+    sizes say so and fall back (still right against the oracle), and the entry point checks its
+    arguments."""
+    from mlx_audio_amd._runtime import get_plan
+    from mlx_audio_amd.primitives.windows import padded_window_np
+    lib = _lib.lib()
+    win = padded_window_np("hann", 2048, 2048)
+    plan = get_plan(torch.device(gpu), 2048, 512, True, "constant", win)
+    assert lib.mia_istft_gated_supported(plan.handle, 9, 2, 4) == 1
+    assert lib.mia_istft_gated_supported(plan.handle, 16, 4, 8) == 1
+    assert lib.mia_istft_gated_supported(plan.handle, 17, 2, 4) == 0
+    assert lib.mia_istft_gated_supported(plan.handle, 9, 5, 4) == 0
+    assert lib.mia_istft_gated_supported(plan.handle, 9, 2, 9) == 0
+    assert lib.mia_istft_gated_supported(plan.handle, 0, 2, 4) == 0
+    other = get_plan(torch.device(gpu), 2048, 256, True, "constant", win)
+    assert lib.mia_istft_gated_supported(other.handle, 9, 2, 4) == 0
+    small = get_plan(torch.device(gpu), 512, 128, True, "constant", padded_window_np("hann", 512, 512))
+    assert lib.mia_istft_gated_supported(small.handle, 3, 2, 4) == 0
+    assert _Ops.fused_windows([("f", 9), ("f", 2), ("t", 4)]) == (9, 2, 4)
+    assert _Ops.fused_windows([("f", 9), ("t", 2), ("f", 2), ("t", 4)]) is None
+    assert _Ops.fused_windows([("t", 4)]) == (1, 1, 4)
+    assert _Ops.fused_windows([]) == (1, 1, 1)
+    s = torch.cuda.current_stream(gpu).cuda_stream
+    spec = torch.zeros((2, 5, 1025), dtype=torch.complex64, device=gpu)
+    thr = torch.ones((2, 1025), device=gpu)
+    out = torch.full((2, 4096), 7.0, device=gpu)
+    args = (1.0, thr.data_ptr(), 2, 0.1, 1, 1.0)
+    assert lib.mia_istft_gated(plan.handle, spec.data_ptr(), 2, 5, 4096, *args, 9, 2, 4, out.data_ptr(), s) == _lib.MIA_OK
+    assert torch.count_nonzero(out).item() == 0
+    assert lib.mia_istft_gated(plan.handle, spec.data_ptr(), 2, 5, 4096, *args, 17, 2, 4, out.data_ptr(), s) == _lib.MIA_ERR_UNSUPPORTED
+    assert lib.mia_istft_gated(plan.handle, spec.data_ptr(), 2, 5, 4096, 1.0, thr.data_ptr(), 3, 0.1, 1, 1.0, 9, 2, 4,
+                               out.data_ptr(), s) == _lib.MIA_ERR_INVALID
+    assert lib.mia_istft_gated(plan.handle, 0, 2, 5, 4096, *args, 9, 2, 4, out.data_ptr(), s) == _lib.MIA_ERR_INVALID
+    out.fill_(7.0)
+    assert lib.mia_istft_gated(plan.handle, spec.data_ptr(), 2, 0, 4096, *args, 9, 2, 4, out.data_ptr(), s) == _lib.MIA_OK
+    assert torch.count_nonzero(out).item() == 0   # no frames: silence
+    # a window wider than the kernel's goes the long way and still matches the oracle
+    y = _noisy()
+    kw = {"freq_smooth_hz": 250.0}
+    got = spectral_gate(_dev(y, gpu), **kw).cpu().numpy()
+    want = orc.spectral_gate(y, **kw)
+    assert np.abs(got - want).max() <= 2e-4 * np.abs(want).max()
+
+
 def test_full_size_batch(gpu):
     """64 x 10 s @22.05 kHz: spot rows against the oracle, batch invariance bit for bit."""
     g = torch.Generator(device=gpu)
