@@ -457,6 +457,16 @@ int mia_gate_mask_box_spec(const void* spec, const float* thr, int64_t rows, int
                            int64_t rows_thr, float gain, int keep, float p, int size_freq, float* out,
                            void* stream);
 
+/* mia_stft with the frame energies the stationary gate ranks its frames by (spectral_gate.py:160,
+ * np.mean(audio_mag ** 2, axis=1)) written beside the spectrum: energy (B, F) = mean over bins of
+ * re^2 + im^2 of the values stored, summed in a fixed order (a shuffle tree per wave, waves in
+ * order), so a row's energies do not depend on the batch around it; equal to
+ * mia_frame_energy_spec on that spectrum to float32 rounding.  Plans of 1024, 2048 and 4096
+ * points (mia_stft_energy_supported; MIA_ERR_UNSUPPORTED otherwise). */
+int mia_stft_energy_supported(const mia_plan* plan);
+int mia_stft_energy(const mia_plan* plan, const float* y, int64_t B, int64_t T, float scale, void* out,
+                    float* energy, void* stream);
+
 /* The stationary gate's mask pipeline and its inverse STFT in one launch (spectral_gate.py:
  * 124-238 from the soft mask to the waveform): spec is the UN-gated STFT, complex64 (B, F, bins)
  * rows as mia_stft writes them, thr (rows_thr, bins) with rows_thr = B or 1, and every bin enters

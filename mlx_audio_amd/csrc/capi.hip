@@ -703,6 +703,30 @@ int mia_stft_moments(const mia_plan* plan, const float* y, int64_t B, int64_t T,
   return launch_forward(plan, p, 5, (hipStream_t)stream);
 }
 
+int mia_stft_energy_supported(const mia_plan* plan) {
+  return plan && !plan->generic && !plan->wave_fft &&
+                 (plan->n_fft == 1024 || plan->n_fft == 2048 || plan->n_fft == 4096)
+             ? 1 : 0;
+}
+
+int mia_stft_energy(const mia_plan* plan, const float* y, int64_t B, int64_t T, float scale, void* out,
+                    float* energy, void* stream) {
+  FwdParams p;
+  int rc = fill_fwd(plan, y, B, T, p);
+  if (rc != MIA_OK) return rc;
+  if (!mia_stft_energy_supported(plan)) {
+    set_error("n_fft=%d has no spectrum + energy kernel (1024, 2048, 4096 have): run mia_stft and "
+              "mia_frame_energy_spec", plan->n_fft);
+    return MIA_ERR_UNSUPPORTED;
+  }
+  if (B == 0) return MIA_OK;
+  MIA_REQUIRE(out && energy, "null pointer");
+  p.scale = scale;
+  p.cout = reinterpret_cast<float2*>(out);
+  p.energy = energy;
+  return launch_forward(plan, p, 7, (hipStream_t)stream);
+}
+
 size_t mia_stft_workspace_bytes(const mia_plan* plan, int64_t B, int64_t T) {
   if (!plan || !plan->generic || plan->wave_fft || B <= 0) return 0;
   const int64_t F = mia_plan_num_frames(plan, T);

@@ -411,13 +411,16 @@ __global__ __launch_bounds__(256) void noise_threshold_spec_kernel(const float2*
   const float2* __restrict__ col = spec + row * F * bins + k;
   const int* __restrict__ sel = idx ? idx + row * n_sel : nullptr;
   const int n = sel ? n_sel : (int)F;
+  // (eight loads in flight per thread: the sums themselves stay in frame order)
   float sum = 0.0f;
+#pragma unroll 8
   for (int q = 0; q < n; ++q) {
     const float2 z = col[(long long)(sel ? sel[q] : q) * bins];
     sum += hypotf(z.x, z.y);
   }
   const float mean = sum / (float)n;
   float ss = 0.0f;
+#pragma unroll 8
   for (int q = 0; q < n; ++q) {
     const float2 z = col[(long long)(sel ? sel[q] : q) * bins];
     const float d = hypotf(z.x, z.y) - mean;

@@ -177,6 +177,7 @@ struct FwdParams {
   // are added to mom_sums[2 * (row / mom_group)] and [... + 1] (double, one atomic pair per tile)
   double* mom_sums;
   int mom_group, mom_bins;
+  float* energy;  // mode 7: (B, F) mean over bins of |X|^2 of every frame, beside the spectrum
   long long mom_f_lo, mom_f_hi;
   int dbg;
   // spectral-statistics epilogue (epi == kEpiStats): centroid, bandwidth, roll-off, flatness

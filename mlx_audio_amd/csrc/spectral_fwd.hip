@@ -323,6 +323,7 @@ __global__ __launch_bounds__(WG, C::OCC) void fwd_kernel(FwdParams p) {
     }
   };
 
+  __shared__ float en_part[MODE == 7 ? FT * (T >= 64 ? T / 64 : 1) : 1];  // MODE 7: per frame and wave
   for (long long idx = first; idx < last; ++idx) {
   double mom_s = 0.0, mom_q = 0.0;  // MODE 5: this thread's share of the tile's moments
   const long long b = (long long)((unsigned)idx / (unsigned)p.tiles);
@@ -494,7 +495,8 @@ __global__ __launch_bounds__(WG, C::OCC) void fwd_kernel(FwdParams p) {
       // (frames past the end exist only in plans whose groups span waves; they took part
       // in the passes for the barriers' sake and produce nothing)
       if (!valid) continue;
-      float2* __restrict__ crow = (MODE == 0 || MODE == 5) ? p.cout + (b * p.F + f) * (long long)(M + 1) : nullptr;
+      float2* __restrict__ crow = (MODE == 0 || MODE == 5 || MODE == 7) ? p.cout + (b * p.F + f) * (long long)(M + 1) : nullptr;
+      float en = 0.0f;  // MODE 7: this thread's share of the frame's sum of |X|^2
       const bool mom_frame = MODE == 5 && f >= p.mom_f_lo && f < p.mom_f_hi;
       float* __restrict__ prow = P + fl * PS;
       const float half_scale = 0.5f * p.scale;
@@ -515,6 +517,10 @@ __global__ __launch_bounds__(WG, C::OCC) void fwd_kernel(FwdParams p) {
           }
 #endif
           store_bin<(C::N >= 2048)>(crow + k, {X.x * half_scale, X.y * half_scale});
+        } else if constexpr (MODE == 7) {
+          const float2 z = {X.x * half_scale, X.y * half_scale};
+          store_bin<(C::N >= 2048)>(crow + k, z);
+          en += __builtin_fmaf(z.x, z.x, z.y * z.y);
         } else if constexpr (MODE == 5) {
           const float2 z = {X.x * half_scale, X.y * half_scale};
           store_bin<(C::N >= 2048)>(crow + k, z);
@@ -547,7 +553,25 @@ __global__ __launch_bounds__(WG, C::OCC) void fwd_kernel(FwdParams p) {
         const float2 Z = (RL % 2 == 0) ? A[RL / 2] : Bv[(RL - 1) / 2];
         emit(M / 2, {2.0f * Z.x, -2.0f * Z.y});
       }
+      if constexpr (MODE == 7) {
+        // the frame's energy: a fixed shuffle tree over each wave, the waves' sums added in order
+        // once the tile is done (a frame is one or more whole waves in the plans that take this mode)
+        static_assert(MODE != 7 || T % 64 == 0, "a frame must be whole waves");
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) en += __shfl_xor(en, off);
+        if ((tid & 63) == 0) en_part[fl * (T / 64) + (t >> 6)] = en;
+      }
     }
+  }
+  if constexpr (MODE == 7) {
+    __syncthreads();
+    if (tid < FT && f0 + tid < p.F) {
+      float sum = en_part[tid * (T / 64)];
+#pragma unroll
+      for (int w = 1; w < T / 64; ++w) sum += en_part[tid * (T / 64) + w];
+      p.energy[b * p.F + f0 + tid] = sum / (float)(M + 1);
+    }
+    __syncthreads();  // the next tile reuses the slots
   }
 
   if constexpr (MODE == 5) {
@@ -575,7 +599,7 @@ __global__ __launch_bounds__(WG, C::OCC) void fwd_kernel(FwdParams p) {
     }
     __syncthreads();  // the next tile reuses the slots
   }
-  if constexpr (MODE != 0) {
+  if constexpr (MODE != 0 && MODE != 7) {
     // Magnitudes or |X|^p instead of powers: one pass over the tile, decided once per tile.  In
     // the split step above the choice was two scalar branches per bin pair, and seventeen
     // inlined copies of powf stood between the hot path's instructions.
@@ -855,7 +879,7 @@ static int launch_cfg(const FwdParams& p0, hipStream_t s) {
   constexpr int PS = (C::M + 1) | 1;
   FwdParams p = p0;
   p.tiles = (int)((p.F + FT - 1) / FT);
-  constexpr bool TILE = MODE != 0 && MODE != 5;  // modes that keep a power / magnitude tile
+  constexpr bool TILE = MODE != 0 && MODE != 5 && MODE != 7;  // modes that keep a power / magnitude tile
   size_t lds = sizeof(float2) * G * C::LBUF + (TILE ? sizeof(float) * FT * PS : 0);
   if (MODE == 2) lds += sizeof(float) * (C::M + 1);  // the bin frequencies
   if (MODE == 1 || MODE == 3) {
@@ -980,6 +1004,17 @@ int launch_forward(const mia_plan* plan, const FwdParams& p, int mode, hipStream
   }
   if (mode == 0) return dispatch_mode<0>(plan->n_fft, p, s);
   if (mode == 5) return dispatch_mode<5>(plan->n_fft, p, s);
+  if (mode == 7) {  // spectrum + frame energies: the plans whose frames are whole waves
+    switch (plan->n_fft) {
+#define X(NFFT, CFG, WG, ITERS) \
+  case NFFT: return launch_cfg<CFG, 7, WG, ITERS>(p, s);
+      MIA_FWD_BIG(X)
+#undef X
+      default:
+        set_error("n_fft=%d has no spectrum + energy kernel (1024, 2048, 4096 have)", plan->n_fft);
+        return MIA_ERR_UNSUPPORTED;
+    }
+  }
   if (mode == 1) return p.frame_major ? dispatch_mode<3>(plan->n_fft, p, s) : dispatch_mode<1>(plan->n_fft, p, s);
   return dispatch_mode<2>(plan->n_fft, p, s);
 }

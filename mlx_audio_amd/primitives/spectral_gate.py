@@ -15,7 +15,7 @@ import torch
 
 from .. import _lib
 from .._runtime import as_device_f32, get_plan, stream_ptr
-from .stft import istft, magnitude, stft
+from .stft import _resolve, istft, magnitude, stft
 from .windows import padded_window_np
 
 
@@ -32,6 +32,7 @@ def _validate(n_fft, hop_length, prop_decrease) -> None:
 
 _SPEC_MASK_MAX_WINDOW = 33   # bins the spectrum form of the mask kernel averages at most
 _FUSE_INVERSE = True         # tests switch the one-launch gate + inverse STFT off to compare
+_FUSE_ENERGY = True          # ... and the frame energies taken inside the forward kernel
 
 
 class _Ops:
@@ -199,6 +200,22 @@ class _Ops:
                   int(windows[0]), int(windows[1]), int(windows[2]), out.data_ptr())
         return out[:, n_fft // 2:n_fft // 2 + n_samples]
 
+    def stft_energy(self, x, n_fft, hop_length, win_length, window):
+        """(stft(x, center=True) as its (rows, bins, frames) view, frame energies (rows, frames))
+        from one launch, or None when the plan has no such kernel."""
+        hop_length, win_length = _resolve(n_fft, hop_length, win_length)
+        plan = get_plan(self.dev, n_fft, hop_length, True, "constant",
+                        padded_window_np(window, win_length, n_fft))
+        if not self.lib.mia_stft_energy_supported(plan.handle):
+            return None
+        rows, n = x.shape
+        frames = plan.num_frames(n)
+        spec = torch.empty((rows, frames, n_fft // 2 + 1), dtype=torch.complex64, device=self.dev)
+        energy = self.new((rows, frames))
+        self._run("mia_stft_energy", plan.handle, x.data_ptr(), rows, n, 1.0, spec.data_ptr(),
+                  energy.data_ptr())
+        return spec.transpose(1, 2), energy
+
     def times(self, a, b):
         out = self.new(a.shape)
         self._run("mia_mask_op", a.data_ptr(), b.data_ptr(), a.numel(), 1, 0.0, out.data_ptr())
@@ -224,8 +241,11 @@ def spectral_gate(audio, noise_profile=None, *, sr: int = 22050, n_fft: int = 20
         x = x[None]
     n_samples = x.shape[-1]
     kw = dict(n_fft=n_fft, hop_length=hop_length, win_length=win_length, window=window, center=True)
-    C = stft(x, **kw)   # a (rows, bins, frames) view of (rows, frames, bins) rows
-    ops = _Ops(C.device)
+    ops = _Ops(x.device)
+    # the stationary estimate ranks the frames by energy: the forward kernel adds it up as it stores
+    both = (ops.stft_energy(x.contiguous(), n_fft, hop_length, win_length, window)
+            if noise_profile is None and stationary and _FUSE_ENERGY and x.shape[-1] > 0 else None)
+    C, energy = both if both is not None else (stft(x, **kw), None)   # C: a (rows, bins, frames) view of (rows, frames, bins) rows
     rows, bins, frames = C.shape
 
     gain = 10 ** (threshold_db / 20.0)
@@ -256,7 +276,8 @@ def spectral_gate(audio, noise_profile=None, *, sr: int = 22050, n_fft: int = 20
         thr = ops.noise_threshold(noise_mag, None, n_std_thresh)
     elif stationary:
         n_quiet = max(1, int(0.1 * frames))
-        energy = ops.frame_energy_spec(spec_rows) if direct else ops.frame_energy(mag)
+        if energy is None:
+            energy = ops.frame_energy_spec(spec_rows) if direct else ops.frame_energy(mag)
         quiet = torch.sort(energy, dim=1, stable=True).indices[:, :n_quiet].to(torch.int32).contiguous()
         thr = (ops.noise_threshold_spec(spec_rows, quiet, n_std_thresh) if direct
                else ops.noise_threshold(mag, quiet, n_std_thresh))

@@ -287,6 +287,37 @@ def test_one_launch_gate_and_inverse_equals_the_separate_launches(gpu, shape):
         assert (one - three).abs().max().item() <= 1e-6 * max(three.abs().max().item(), 1e-3), case
 
 
+@pytest.mark.parametrize("n_fft,hop", [(2048, 512), (1024, 256), (4096, 1024), (2048, 300)])
+def test_frame_energies_from_the_forward_kernel(gpu, n_fft, hop):
+    """mia_stft_energy: the spectrum bit for bit mia_stft's, the energies those of the separate
+    kernel on that spectrum to float32 rounding, rows independent of the batch around them, rows
+    that end inside a tile and clips shorter than a frame included."""
+    from mlx_audio_amd.primitives import stft
+    g = torch.Generator(device=gpu)
+    g.manual_seed(n_fft + hop)
+    for rows, n in [(3, 30000), (1, 700), (5, n_fft * 3 + 17)]:
+        x = torch.randn((rows, n), generator=g, device=gpu)
+        ops = _Ops(torch.device(gpu))
+        spec, energy = ops.stft_energy(x, n_fft, hop, n_fft, "hann")
+        ref = stft(x, n_fft=n_fft, hop_length=hop)
+        assert torch.equal(torch.view_as_real(spec.contiguous()), torch.view_as_real(ref.contiguous()))
+        want = ops.frame_energy_spec(ref.transpose(1, 2))
+        np.testing.assert_allclose(energy.cpu().numpy(), want.cpu().numpy(), rtol=3e-6)
+        mag = np.abs(ref.cpu().numpy())
+        np.testing.assert_allclose(energy.cpu().numpy(), np.mean(mag.astype(np.float64) ** 2, axis=1), rtol=3e-6)
+        alone = ops.stft_energy(x[rows - 1:].contiguous(), n_fft, hop, n_fft, "hann")[1]
+        assert torch.equal(alone[0], energy[rows - 1])
+    lib = _lib.lib()
+    from mlx_audio_amd._runtime import get_plan
+    from mlx_audio_amd.primitives.windows import padded_window_np
+    small = get_plan(torch.device(gpu), 512, 128, True, "constant", padded_window_np("hann", 512, 512))
+    assert lib.mia_stft_energy_supported(small.handle) == 0
+    assert _Ops(torch.device(gpu)).stft_energy(torch.zeros((1, 4000), device=gpu), 512, 128, 512, "hann") is None
+    s = torch.cuda.current_stream(gpu).cuda_stream
+    z = torch.zeros((1, 4000), device=gpu)
+    assert lib.mia_stft_energy(small.handle, z.data_ptr(), 1, 4000, 1.0, z.data_ptr(), z.data_ptr(), s) == _lib.MIA_ERR_UNSUPPORTED
+
+
 def test_one_launch_gate_is_the_path_taken(gpu):
     """The default call's framing and windows have the one-launch kernel, wider windows and other
     sizes say so and fall back (still right against the oracle), and the entry point checks its
