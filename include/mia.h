@@ -457,6 +457,14 @@ int mia_gate_mask_box_spec(const void* spec, const float* thr, int64_t rows, int
                            int64_t rows_thr, float gain, int keep, float p, int size_freq, float* out,
                            void* stream);
 
+/* The stationary estimate's choice of frames (spectral_gate.py:166, np.argsort(frame_energy[b])
+ * [:n_quiet]): frame_idx (rows, n_selected) int32 = the frames with the smallest energies of each
+ * row of energy (rows, frames), ascending, equal energies in frame order (a stable sort's
+ * choice; the reference's unstable sort leaves it open), NaN last.  Rows of up to 8192 frames;
+ * MIA_ERR_UNSUPPORTED beyond (the caller sorts). */
+int mia_quietest_frames(const float* energy, int64_t rows, int64_t frames, int n_selected, int* frame_idx,
+                        void* stream);
+
 /* mia_stft with the frame energies the stationary gate ranks its frames by (spectral_gate.py:160,
  * np.mean(audio_mag ** 2, axis=1)) written beside the spectrum: energy (B, F) = mean over bins of
  * re^2 + im^2 of the values stored, summed in a fixed order (a shuffle tree per wave, waves in
@@ -474,8 +482,8 @@ int mia_stft_energy(const mia_plan* plan, const float* y, int64_t B, int64_t T, 
  * averaged over size_freq bins, then over size_freq2 bins, then over size_time frames (each a
  * mia_box_filter: ends repeated, 1 = none) and m' = keep ? 1 - p (1 - m) : m.  Neither the mask
  * nor the gated spectrum is written anywhere; the result equals mia_gate_mask_box_spec +
- * mia_gate_apply_spectrum + mia_istft to float32 rounding.  Plans of 1024 and 2048 points at
- * hop n_fft / 4, windows of up to 33 / 4 bins and 8 frames (mia_istft_gated_supported says so;
+ * mia_gate_apply_spectrum + mia_istft to float32 rounding.  Plans of 1024, 2048 and 4096 points
+ * at hop n_fft / 4, windows of up to 16 / 4 bins and 8 frames (mia_istft_gated_supported says so;
  * MIA_ERR_UNSUPPORTED otherwise).  out (B, out_len) as mia_istft's, no workspace. */
 int mia_istft_gated_supported(const mia_plan* plan, int size_freq, int size_freq2, int size_time);
 int mia_istft_gated(const mia_plan* plan, const void* spec, int64_t B, int64_t F, int64_t out_len,

@@ -128,6 +128,7 @@ SIGNATURES = {
                                          c_void_p, c_void_p]),
     "mia_gate_mask_box_spec": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int64, c_int64, c_float,
                                        c_int, c_float, c_int, c_void_p, c_void_p]),
+    "mia_quietest_frames": (c_int, [c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p]),
     "mia_stft_energy_supported": (c_int, [c_void_p]),
     "mia_stft_energy": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_float, c_void_p, c_void_p,
                                 c_void_p]),

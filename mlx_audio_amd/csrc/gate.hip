@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void noise_threshold_kernel(const float* __res
   float ss = 0.0f;
   for (int q = 0; q < n; ++q) {
     const float d = line[sel ? sel[q] : q] - mean;
-    ss += d * d;
+    ss = __builtin_fmaf(d, d, ss);
   }
   thr[g] = mean + n_std * sqrtf(ss / (float)n);
 }
@@ -400,33 +400,59 @@ __global__ __launch_bounds__(256) void frame_energy_spec_kernel(const float2* __
 
 // thr[row, bin] = mean + n_std * std (population) of |spec[row, idx[row, q], bin]|, q < n_sel (idx ==
 // nullptr: every frame), summed in the order noise_threshold_kernel sums them: bit-identical to
-// it on the magnitude plane.  One thread per bin, so a frame's values are read as one run.
+// it on the magnitude plane.  A block takes 64 bins of a row: its four waves turn 64 frames'
+// values at a time into magnitudes in LDS (sixteen independent loads per thread, each a run of
+// 64 complex values), then one thread per bin adds them up in frame order - the sums are
+// serial by definition, the loads and square roots in front of them are not.
+constexpr int kThrBins = 64, kThrFrames = 64;
 __global__ __launch_bounds__(256) void noise_threshold_spec_kernel(const float2* __restrict__ spec,
-                                                                   long long rows, int bins, long long F,
+                                                                   int bins, long long F,
                                                                    const int* __restrict__ idx, int n_sel,
                                                                    float n_std, float* __restrict__ thr) {
-  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= rows * bins) return;
-  const long long row = g / bins, k = g - row * bins;
-  const float2* __restrict__ col = spec + row * F * bins + k;
+  __shared__ float mags[kThrFrames][kThrBins];
+  __shared__ float means[kThrBins];
+  const long long row = blockIdx.y;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int k = blockIdx.x * kThrBins + lane;
+  const int kc = k < bins ? k : bins - 1;
+  const float2* __restrict__ col = spec + row * F * bins + kc;
   const int* __restrict__ sel = idx ? idx + row * n_sel : nullptr;
   const int n = sel ? n_sel : (int)F;
-  // (eight loads in flight per thread: the sums themselves stay in frame order)
+  auto stage = [&](int c0) {  // magnitudes of frames c0 .. c0 + 63 of the selection
+#pragma unroll
+    for (int i = 0; i < kThrFrames / 4; ++i) {
+      const int q = w + 4 * i;
+      if (c0 + q < n) {
+        const float2 z = col[(long long)(sel ? sel[c0 + q] : c0 + q) * bins];
+        mags[q][lane] = hypotf(z.x, z.y);
+      }
+    }
+    __syncthreads();
+  };
   float sum = 0.0f;
-#pragma unroll 8
-  for (int q = 0; q < n; ++q) {
-    const float2 z = col[(long long)(sel ? sel[q] : q) * bins];
-    sum += hypotf(z.x, z.y);
+  for (int c0 = 0; c0 < n; c0 += kThrFrames) {
+    stage(c0);
+    if (w == 0) {
+      const int m = n - c0 < kThrFrames ? n - c0 : kThrFrames;
+      for (int q = 0; q < m; ++q) sum += mags[q][lane];
+    }
+    __syncthreads();
   }
-  const float mean = sum / (float)n;
+  if (w == 0) means[lane] = sum / (float)n;
   float ss = 0.0f;
-#pragma unroll 8
-  for (int q = 0; q < n; ++q) {
-    const float2 z = col[(long long)(sel ? sel[q] : q) * bins];
-    const float d = hypotf(z.x, z.y) - mean;
-    ss += d * d;
+  for (int c0 = 0; c0 < n; c0 += kThrFrames) {
+    if (n > kThrFrames || c0 > 0) stage(c0); else __syncthreads();  // a single chunk is still there
+    if (w == 0) {
+      const float mean = means[lane];
+      const int m = n - c0 < kThrFrames ? n - c0 : kThrFrames;
+      for (int q = 0; q < m; ++q) {
+        const float d = mags[q][lane] - mean;
+        ss = __builtin_fmaf(d, d, ss);
+      }
+    }
+    __syncthreads();
   }
-  thr[g] = mean + n_std * sqrtf(ss / (float)n);
+  if (w == 0 && k < bins) thr[row * bins + k] = means[lane] + n_std * sqrtf(ss / (float)n);
 }
 
 // gate_mask_box_tiled_kernel with the magnitudes taken from the spectrum: the tile's bins (and
@@ -474,6 +500,37 @@ __global__ __launch_bounds__(256) void gate_mask_box_spec_kernel(
     double sum = 0.0;
     for (int j = 0; j < size; ++j) sum += (double)vt[kl + j][fx];
     out[oplane + (size_t)k * F + f] = size == 1 ? (float)sum : window_mean(sum, inv);
+  }
+}
+
+// idx[row, r] = the frame with the r-th smallest energy of its row, r < n_sel, equal energies in
+// frame order (a stable ascending sort's first n_sel indices; NaN sorts last).  A frame's rank
+// is the count of frames that sort before it, counted against the row's keys in LDS (every lane
+// reads the same key: a broadcast).  A block ranks 64 frames, its four waves a quarter of the
+// row each - a few hundred frames a row, where a general sort spends most of its time in launches.
+constexpr int kQuietMaxFrames = 8192;
+__global__ __launch_bounds__(256) void quietest_frames_kernel(const float* __restrict__ energy, int F,
+                                                              int n_sel, int* __restrict__ idx) {
+  extern __shared__ int quiet_keys[];  // F keys, then 4 x 64 partial ranks
+  int* part = quiet_keys + F;
+  const long long row = blockIdx.y;
+  for (int i = threadIdx.x; i < F; i += 256) quiet_keys[i] = float_to_key_nan(energy[row * F + i] + 0.0f);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + lane;
+  const int ki = quiet_keys[i < F ? i : F - 1];
+  const int per = (F + 3) / 4, j0 = w * per, j1 = j0 + per < F ? j0 + per : F;
+  int rank = 0;
+#pragma unroll 8
+  for (int j = j0; j < j1; ++j) {
+    const int kj = quiet_keys[j];
+    rank += (kj < ki || (kj == ki && j < i)) ? 1 : 0;
+  }
+  part[w * 64 + lane] = rank;
+  __syncthreads();
+  if (w == 0 && i < F) {
+    rank = part[lane] + part[64 + lane] + part[128 + lane] + part[192 + lane];
+    if (rank < n_sel) idx[row * n_sel + rank] = i;
   }
 }
 
@@ -685,10 +742,39 @@ int mia_noise_threshold_spec(const void* spec, int64_t rows, int bins, int64_t f
   MIA_REQUIRE(frames <= 0x7fffffffLL, "too many frames");
   if (rows == 0) return MIA_OK;
   MIA_REQUIRE(spec && thr, "null pointer");
-  hipLaunchKernelGGL(noise_threshold_spec_kernel, dim3(gate_blocks(rows * bins)), dim3(256), 0,
-                     (hipStream_t)stream, (const float2*)spec, (long long)rows, bins, (long long)frames,
-                     frame_idx, n_selected, n_std, thr);
-  MIA_CHECK_HIP(hipGetLastError());
+  const unsigned chunks = (unsigned)((bins + kThrBins - 1) / kThrBins);
+  for (int64_t r0 = 0; r0 < rows; r0 += 65535) {  // a launch takes at most 65535 rows
+    const int64_t nr = rows - r0 < 65535 ? rows - r0 : 65535;
+    hipLaunchKernelGGL(noise_threshold_spec_kernel, dim3(chunks, (unsigned)nr), dim3(256), 0,
+                       (hipStream_t)stream, (const float2*)spec + (size_t)r0 * frames * bins, bins,
+                       (long long)frames, frame_idx ? frame_idx + (size_t)r0 * n_selected : nullptr,
+                       n_selected, n_std, thr + (size_t)r0 * bins);
+    MIA_CHECK_HIP(hipGetLastError());
+  }
+  return MIA_OK;
+}
+
+int mia_quietest_frames(const float* energy, int64_t rows, int64_t frames, int n_selected, int* frame_idx,
+                        void* stream) {
+  using namespace mia;
+  MIA_REQUIRE(rows >= 0 && frames >= 1, "rows, frames must be >= 0, 1");
+  MIA_REQUIRE(n_selected >= 1 && n_selected <= frames, "n_selected must be in [1, frames], got %d", n_selected);
+  if (frames > kQuietMaxFrames) {
+    set_error("rows of %lld frames: this kernel ranks at most %d (sort the energies instead)",
+              (long long)frames, kQuietMaxFrames);
+    return MIA_ERR_UNSUPPORTED;
+  }
+  if (rows == 0) return MIA_OK;
+  MIA_REQUIRE(energy && frame_idx, "null pointer");
+  const unsigned chunks = (unsigned)((frames + 63) / 64);
+  for (int64_t r0 = 0; r0 < rows; r0 += 65535) {  // a launch takes at most 65535 rows
+    const int64_t nr = rows - r0 < 65535 ? rows - r0 : 65535;
+    hipLaunchKernelGGL(quietest_frames_kernel, dim3(chunks, (unsigned)nr), dim3(256),
+                       sizeof(int) * ((size_t)frames + 256), (hipStream_t)stream,
+                       energy + (size_t)r0 * frames, (int)frames, n_selected,
+                       frame_idx + (size_t)r0 * n_selected);
+    MIA_CHECK_HIP(hipGetLastError());
+  }
   return MIA_OK;
 }
 

@@ -614,16 +614,30 @@ __device__ __forceinline__ float gate_abs(float2 z) {
 #endif
 }
 
-// m1[i] = mean of w[i .. i + S1 - 1], i < kGateNO: the window's double-precision sum in
-// ascending order times 1 / S1, as box_filter_kernel takes it.
+// m1[i] = mean of w[i .. i + S1 - 1], i < kGateNO: the window's double-precision sum times 1 / S1,
+// as box_filter_kernel takes it.  The sum slides (one value in, one out): sums of up to sixteen
+// float32 mask values are exact in double precision unless one of them is below 2^-25 of the
+// largest, so this is the ascending sum to the last bit wherever that bit means anything.
 template <int S1>
-__device__ __forceinline__ void gate_window_means(const float (&w)[kGateNW], float (&m1)[kGateNO], double inv) {
+__device__ __forceinline__ void gate_window_means(const float* __restrict__ src, int first,
+                                                  float (&m1)[kGateNO], double inv) {
+  float w[kGateNO + S1 - 1];  // element i of the row sits at i + i / 8
 #pragma unroll
-  for (int i = 0; i < kGateNO; ++i) {
+  for (int x = 0; x < kGateNO + S1 - 1; ++x) w[x] = src[gate_pos(first + x)];
+  if constexpr (S1 == 1) {
+#pragma unroll
+    for (int i = 0; i < kGateNO; ++i) m1[i] = w[i];
+  } else {
     double sum = 0.0;
 #pragma unroll
-    for (int j = 0; j < S1; ++j) sum += (double)w[i + j];
-    m1[i] = S1 == 1 ? (float)sum : window_mean(sum, inv);
+    for (int j = 0; j < S1; ++j) sum += (double)w[j];
+    m1[0] = window_mean(sum, inv);
+#pragma unroll
+    for (int i = 1; i < kGateNO; ++i) {
+      sum += (double)w[i + S1 - 1];
+      sum -= (double)w[i - 1];
+      m1[i] = window_mean(sum, inv);
+    }
   }
 }
 
@@ -689,8 +703,9 @@ __global__ __launch_bounds__(C::T, 2) void istft_gate_kernel(InvParams p, GatePa
   // A row's spectrum values are fetched a row ahead (they arrive behind a transform): mz holds
   // bins t + i WG of frame pf_f of row pf_b, mzM bin M (last thread).
   float2 mz[8], mzM = {0.0f, 0.0f};
-  long long pf_b = -1;
+  long long pf_b = -1, th_b = -1;
   int pf_f = -1;
+  float thv[8], thM = 0.0f;
   auto fetch_row = [&](long long b, int fr) {
     const float2* __restrict__ zr = p.spec + b * p.sb + (long long)fr * p.sf;
 #pragma unroll
@@ -699,40 +714,46 @@ __global__ __launch_bounds__(C::T, 2) void istft_gate_kernel(InvParams p, GatePa
     pf_b = b;
     pf_f = fr;
   };
-  // tmp0[gate_pos(kGateMaxS2 / 2 + h1 + k)] = mask value of bin k, the ends repeated h1 and
-  // (s1 - 1) / 2 times; the window of the first average at bin e starts at kGateMaxS2 / 2 + e.
+  // tmp0[gate_pos(kGateMaxS2 / 2 + h1 + k)] = mask value of bin k, the end values repeated on
+  // both sides; the window of the first average at bin e starts at kGateMaxS2 / 2 + e.
   constexpr int SH = kGateMaxS2 / 2;
   auto mask_row = [&](long long b, int fr) {
     if (pf_b != b || pf_f != fr) fetch_row(b, fr);
-    const float* __restrict__ th = g.thr + b * g.thr_stride;
+    if (th_b != b) {  // the row's thresholds stay in registers for all of its frames
+      const float* __restrict__ th = g.thr + b * g.thr_stride;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) thv[i] = th[t + i * WG];
+      thM = th[M];
+      th_b = b;
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int k = t + i * WG;
-      const float v = gate_mask_value(gate_abs(mz[i]), th[k], g.gain);
+      const float v = gate_mask_value(gate_abs(mz[i]), thv[i], g.gain);
       tmp0[gate_pos(SH + h1 + k)] = v;
       if (k == 0) {
-        for (int j = 0; j < h1; ++j) tmp0[gate_pos(SH + j)] = v;
+        for (int j = 0; j < SH + h1; ++j) tmp0[gate_pos(j)] = v;
       }
     }
     if (t == WG - 1) {
-      const float v = gate_mask_value(gate_abs(mzM), th[M], g.gain);
-      for (int j = 0; j <= (s1 - 1) / 2; ++j) tmp0[gate_pos(SH + h1 + M + j)] = v;
+      // (the end value goes on past the window's reach to the last element any thread reads: the
+      // sliding sums must never take in what an earlier transform left here)
+      const float v = gate_mask_value(gate_abs(mzM), thM, g.gain);
+      for (int j = 0; j <= s1 + 2; ++j) tmp0[gate_pos(SH + h1 + M + j)] = v;
     }
     if (fr + 1 < nF) fetch_row(b, fr + 1);
     __syncthreads();
     // thread t: bins 8 t .. 8 t + 7 (the last thread also bin M).  Its first averages are those
     // at bins e0 + i, e0 = 8 t - s2 / 2; beyond the ends they repeat the end's.
     const int e0 = 8 * t - h2;
-    float w[kGateNW], m1[kGateNO];
-#pragma unroll
-    for (int x = 0; x < kGateNW; ++x) w[x] = tmp0[gate_pos(SH + e0 + x)];
+    float m1[kGateNO];
     switch (s1) {
-#define MIA_GATE_S1(S) case S: gate_window_means<S>(w, m1, inv1); break;
+#define MIA_GATE_S1(S) case S: gate_window_means<S>(tmp0, SH + e0, m1, inv1); break;
       MIA_GATE_S1(1) MIA_GATE_S1(2) MIA_GATE_S1(3) MIA_GATE_S1(4) MIA_GATE_S1(5) MIA_GATE_S1(6)
       MIA_GATE_S1(7) MIA_GATE_S1(8) MIA_GATE_S1(9) MIA_GATE_S1(10) MIA_GATE_S1(11) MIA_GATE_S1(12)
       MIA_GATE_S1(13) MIA_GATE_S1(14) MIA_GATE_S1(15)
 #undef MIA_GATE_S1
-      default: gate_window_means<16>(w, m1, inv1); break;
+      default: gate_window_means<16>(tmp0, SH + e0, m1, inv1); break;
     }
     if (t == 0) {  // bins below 0: the average at bin 0, which is m1[h2]
       const float at0 = h2 == 2 ? m1[2] : (h2 == 1 ? m1[1] : m1[0]);
@@ -1004,9 +1025,9 @@ static int launch_gated_own(const InvParams& p0, const GateParams& g, hipStream_
   return MIA_OK;
 }
 
-// The gate inside the inverse: 1024 and 2048 points at hop n_fft / 4, windows the rows in LDS hold.
+// The gate inside the inverse: 1024, 2048 and 4096 points at hop n_fft / 4, windows the rows in LDS hold.
 bool istft_gated_supported(int n_fft, int hop, int s1, int s2, int st) {
-  return (n_fft == 1024 || n_fft == 2048) && hop * 4 == n_fft && s1 >= 1 && s1 <= kGateMaxS1 &&
+  return (n_fft == 1024 || n_fft == 2048 || n_fft == 4096) && hop * 4 == n_fft && s1 >= 1 && s1 <= kGateMaxS1 &&
          s2 >= 1 && s2 <= kGateMaxS2 && st >= 1 && st <= kGateMaxSt;
 }
 
@@ -1016,8 +1037,11 @@ int launch_istft_gated(const mia_plan* plan, const InvParams& p, const GateParam
               g.s2, g.st);
     return MIA_ERR_UNSUPPORTED;
   }
-  return plan->n_fft == 1024 ? launch_gated_own<Inv1024, MIA_GATE_FT>(p, g, s)
-                             : launch_gated_own<Inv2048, MIA_GATE_FT>(p, g, s);
+  switch (plan->n_fft) {
+    case 1024: return launch_gated_own<Inv1024, MIA_GATE_FT>(p, g, s);
+    case 2048: return launch_gated_own<Inv2048, MIA_GATE_FT>(p, g, s);
+    default: return launch_gated_own<Inv4096, MIA_GATE_FT>(p, g, s);
+  }
 }
 
 // The framings a fused kernel covers: hop = n_fft / 4 with hop a multiple of 256 on the compiled

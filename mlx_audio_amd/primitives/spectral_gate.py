@@ -31,6 +31,7 @@ def _validate(n_fft, hop_length, prop_decrease) -> None:
 
 
 _SPEC_MASK_MAX_WINDOW = 33   # bins the spectrum form of the mask kernel averages at most
+_QUIET_MAX_FRAMES = 8192     # frames per row the ranking kernel takes
 _FUSE_INVERSE = True         # tests switch the one-launch gate + inverse STFT off to compare
 _FUSE_ENERGY = True          # ... and the frame energies taken inside the forward kernel
 
@@ -200,6 +201,16 @@ class _Ops:
                   int(windows[0]), int(windows[1]), int(windows[2]), out.data_ptr())
         return out[:, n_fft // 2:n_fft // 2 + n_samples]
 
+    def quietest(self, energy, n_quiet):
+        """Indices (rows, n_quiet) int32 of each row's n_quiet smallest energies, ascending, ties
+        in frame order."""
+        rows, frames = energy.shape
+        if frames > _QUIET_MAX_FRAMES:   # long rows: a general (stable) sort
+            return torch.sort(energy, dim=1, stable=True).indices[:, :n_quiet].to(torch.int32).contiguous()
+        out = torch.empty((rows, n_quiet), dtype=torch.int32, device=self.dev)
+        self._run("mia_quietest_frames", energy.data_ptr(), rows, frames, int(n_quiet), out.data_ptr())
+        return out
+
     def stft_energy(self, x, n_fft, hop_length, win_length, window):
         """(stft(x, center=True) as its (rows, bins, frames) view, frame energies (rows, frames))
         from one launch, or None when the plan has no such kernel."""
@@ -278,7 +289,7 @@ def spectral_gate(audio, noise_profile=None, *, sr: int = 22050, n_fft: int = 20
         n_quiet = max(1, int(0.1 * frames))
         if energy is None:
             energy = ops.frame_energy_spec(spec_rows) if direct else ops.frame_energy(mag)
-        quiet = torch.sort(energy, dim=1, stable=True).indices[:, :n_quiet].to(torch.int32).contiguous()
+        quiet = ops.quietest(energy, n_quiet)
         thr = (ops.noise_threshold_spec(spec_rows, quiet, n_std_thresh) if direct
                else ops.noise_threshold(mag, quiet, n_std_thresh))
     else:

@@ -252,7 +252,7 @@ def test_behaviour_and_c_abi_checks(gpu):
 
 
 _ONE_LAUNCH_CASES = [
-    {}, {"n_fft": 1024}, {"sr": 16000}, {"sr": 44100, "n_grad_freq": 3, "n_grad_time": 5, "prop_decrease": 0.8},
+    {}, {"n_fft": 1024}, {"n_fft": 4096, "sr": 44100}, {"sr": 16000}, {"sr": 44100, "n_grad_freq": 3, "n_grad_time": 5, "prop_decrease": 0.8},
     {"n_grad_freq": 1, "n_grad_time": 1}, {"freq_smooth_hz": 0.0, "time_smooth_ms": 0.0},
     {"n_grad_freq": 4, "n_grad_time": 8, "freq_smooth_hz": 172.0}, {"noise": True},
     {"window": "hamming", "win_length": 1500, "prop_decrease": 0.5},
@@ -316,6 +316,33 @@ def test_frame_energies_from_the_forward_kernel(gpu, n_fft, hop):
     s = torch.cuda.current_stream(gpu).cuda_stream
     z = torch.zeros((1, 4000), device=gpu)
     assert lib.mia_stft_energy(small.handle, z.data_ptr(), 1, 4000, 1.0, z.data_ptr(), z.data_ptr(), s) == _lib.MIA_ERR_UNSUPPORTED
+
+
+def test_quietest_frames_are_a_stable_sorts_first(gpu):
+    """mia_quietest_frames against torch's stable sort: random rows, rows full of ties, NaN and
+    infinities, one frame, n_selected = frames; long rows fall back to the sort."""
+    ops = _Ops(torch.device(gpu))
+    g = torch.Generator(device=gpu)
+    g.manual_seed(11)
+    for rows, frames in [(3, 431), (1, 1), (2, 7), (5, 1000), (1, 8192)]:
+        e = torch.rand((rows, frames), generator=g, device=gpu)
+        e[:, ::3] = torch.round(e[:, ::3] * 4) / 4          # many exact ties
+        if frames > 6:
+            e[0, 2] = float("nan"); e[0, 5] = float("inf"); e[-1, 1] = 0.0; e[-1, 4] = -0.0
+        for n_sel in sorted({1, max(1, frames // 10), frames}):
+            got = ops.quietest(e, n_sel)
+            want = torch.sort(e, dim=1, stable=True).indices[:, :n_sel].to(torch.int32)
+            assert got.dtype == torch.int32 and torch.equal(got, want), (rows, frames, n_sel)
+    long_row = torch.rand((1, 9000), generator=g, device=gpu)
+    assert torch.equal(ops.quietest(long_row, 900),
+                       torch.sort(long_row, dim=1, stable=True).indices[:, :900].to(torch.int32))
+    lib = _lib.lib()
+    s = torch.cuda.current_stream(gpu).cuda_stream
+    out = torch.zeros((1, 9000), dtype=torch.int32, device=gpu)
+    assert lib.mia_quietest_frames(long_row.data_ptr(), 1, 9000, 10, out.data_ptr(), s) == _lib.MIA_ERR_UNSUPPORTED
+    assert lib.mia_quietest_frames(long_row.data_ptr(), 1, 100, 0, out.data_ptr(), s) == _lib.MIA_ERR_INVALID
+    assert lib.mia_quietest_frames(long_row.data_ptr(), 1, 100, 101, out.data_ptr(), s) == _lib.MIA_ERR_INVALID
+    assert lib.mia_quietest_frames(0, 0, 100, 10, 0, s) == _lib.MIA_OK
 
 
 def test_one_launch_gate_is_the_path_taken(gpu):
