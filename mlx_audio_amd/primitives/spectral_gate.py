@@ -32,6 +32,7 @@ def _validate(n_fft, hop_length, prop_decrease) -> None:
 
 _SPEC_MASK_MAX_WINDOW = 33   # bins the spectrum form of the mask kernel averages at most
 _QUIET_MAX_FRAMES = 8192     # frames per row the ranking kernel takes
+_FUSED_MAX_FRAMES, _FUSED_MAX_FRAMES_4096 = 7, 4   # time windows up to which the one-launch gate wins
 _FUSE_INVERSE = True         # tests switch the one-launch gate + inverse STFT off to compare
 _FUSE_ENERGY = True          # ... and the frame energies taken inside the forward kernel
 
@@ -189,6 +190,10 @@ class _Ops:
         or the windows have no such kernel.  spec: the (rows, bins, frames) view stft() returns."""
         spec_rows = spec.transpose(1, 2)
         if not spec_rows.is_contiguous() or thr.dim() != 2:
+            return None
+        # the kernel keeps windows[2] rows of mask values in LDS: past these lengths it holds too few
+        # workgroups per CU and the separate launches are the faster ones (tools/time_gate_inverse.py)
+        if windows[2] > (_FUSED_MAX_FRAMES_4096 if n_fft >= 4096 else _FUSED_MAX_FRAMES):
             return None
         plan = get_plan(self.dev, n_fft, hop_length, True, "constant",
                         padded_window_np(window, win_length, n_fft))

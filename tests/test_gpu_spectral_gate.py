@@ -254,7 +254,8 @@ def test_behaviour_and_c_abi_checks(gpu):
 _ONE_LAUNCH_CASES = [
     {}, {"n_fft": 1024}, {"n_fft": 4096, "sr": 44100}, {"sr": 16000}, {"sr": 44100, "n_grad_freq": 3, "n_grad_time": 5, "prop_decrease": 0.8},
     {"n_grad_freq": 1, "n_grad_time": 1}, {"freq_smooth_hz": 0.0, "time_smooth_ms": 0.0},
-    {"n_grad_freq": 4, "n_grad_time": 8, "freq_smooth_hz": 172.0}, {"noise": True},
+    {"n_grad_freq": 4, "n_grad_time": 8, "freq_smooth_hz": 172.0}, {"n_fft": 4096, "sr": 44100, "n_grad_time": 6},
+    {"noise": True},
     {"window": "hamming", "win_length": 1500, "prop_decrease": 0.5},
 ]
 
@@ -272,17 +273,20 @@ def test_one_launch_gate_and_inverse_equals_the_separate_launches(gpu, shape):
     x = 0.05 * torch.randn(shape, generator=g, device=gpu)
     t = torch.arange(shape[1], device=gpu) / 22050.0
     x = x + 0.5 * torch.sin(2 * np.pi * 440 * t) * (t > 0.4 * shape[1] / 22050.0)
+    limits = mod._FUSED_MAX_FRAMES, mod._FUSED_MAX_FRAMES_4096
     for case in _ONE_LAUNCH_CASES:
         kw = dict(case)
         if kw.pop("noise", False):
             kw["noise_profile"] = 0.05 * torch.randn(8000, generator=g, device=gpu)
         assert mod._FUSE_INVERSE
-        one = spectral_gate(x, **kw)
         try:
+            mod._FUSED_MAX_FRAMES = mod._FUSED_MAX_FRAMES_4096 = 8   # every time window the kernel takes
+            one = spectral_gate(x, **kw)
             mod._FUSE_INVERSE = False
             three = spectral_gate(x, **kw)
         finally:
             mod._FUSE_INVERSE = True
+            mod._FUSED_MAX_FRAMES, mod._FUSED_MAX_FRAMES_4096 = limits
         assert one.shape == three.shape == x.shape
         assert (one - three).abs().max().item() <= 1e-6 * max(three.abs().max().item(), 1e-3), case
 
@@ -368,6 +372,12 @@ def test_one_launch_gate_is_the_path_taken(gpu):
     assert _Ops.fused_windows([("f", 9), ("t", 2), ("f", 2), ("t", 4)]) is None
     assert _Ops.fused_windows([("t", 4)]) == (1, 1, 4)
     assert _Ops.fused_windows([]) == (1, 1, 1)
+    # time windows the kernel takes but runs slower than the separate launches: the mirror goes the long way
+    ops = _Ops(torch.device(gpu))
+    C8 = torch.zeros((1, 6, 1025), dtype=torch.complex64, device=gpu).transpose(1, 2)
+    thr8 = torch.ones((1, 1025), device=gpu)
+    assert ops.gated_istft(C8, thr8, 0.1, (9, 2, 8), 1.0, 2048, 512, 2048, "hann", 2000) is None
+    assert ops.gated_istft(C8, thr8, 0.1, (9, 2, 7), 1.0, 2048, 512, 2048, "hann", 2000) is not None
     s = torch.cuda.current_stream(gpu).cuda_stream
     spec = torch.zeros((2, 5, 1025), dtype=torch.complex64, device=gpu)
     thr = torch.ones((2, 1025), device=gpu)
