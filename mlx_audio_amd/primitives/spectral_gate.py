@@ -3,9 +3,12 @@
 
 The reference computes the STFT on its array library, moves magnitude and phase to the host,
 builds the gate mask in NumPy / scipy.ndimage and goes back for the inverse STFT.  Here every
-step stays on the GPU, the choice of the quietest tenth of the frames included (a stable device
-sort of one number per frame), and the phase is never taken apart: magnitude * exp(i phase) is
-the spectrum itself, so the gated spectrum is the STFT scaled by the mask.
+step stays on the GPU, the choice of the quietest tenth of the frames included (the order of a
+stable sort of one number per frame), and the phase is never taken apart: magnitude * exp(i phase)
+is the spectrum itself, so the gated spectrum is the STFT scaled by the mask.  The default call -
+a per-bin threshold and at most two averages over bins and one over frames - is four launches:
+the STFT with the frame energies beside it, the ranking of the frames, the threshold, and an
+inverse STFT that builds and applies the mask as it reads the spectrum.
 """
 
 from __future__ import annotations
