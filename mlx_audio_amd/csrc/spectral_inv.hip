@@ -925,8 +925,13 @@ using Inv800 = MIA_INV800;
 // (128 rows x 180 s) against the three-pass plan <4096, 128, 8, 16, 16> with table twiddles and
 // two frames per workgroup: inverse 9.9 -> 5.3 ms.  The table loads in front of
 // every pass were the difference: the same four-pass plan with table twiddles took 11.2 ms.
-using Inv1024 = InvCfg<1024, 64, 4, 8, 4, 8, 4>;
-using Inv2048 = InvCfg<2048, 128, 4, 8, 8, 8, 4>;
+// LDS layout (tools/ab_inv.sh, fused inverse of 256 x 30 s): one pad slot per 16 elements instead
+// of per 8 takes the 1024-point plan from 0.90 to 0.63 ms (as in the forward plan of that size,
+// the compiler pairs its LDS accesses, and pairs 8 elements apart collide) and the 2048-point
+// plan from 0.89 to 0.87; at 4096 points the two are equal (5.38 ms for 128 rows x 180 s), one
+// per 32 or per 4 loses everywhere.
+using Inv1024 = InvCfg<1024, 64, 4, 8, 4, 16, 4>;
+using Inv2048 = InvCfg<2048, 128, 4, 8, 8, 16, 4>;
 using Inv4096 = InvCfg<4096, 256, 4, 8, 8, 8, 8>;
 
 template <class C, int WG, int ITERS>
