@@ -289,10 +289,13 @@ def spectral_gate(audio, noise_profile=None, *, sr: int = 22050, n_fft: int = 20
 
     if noise_profile is not None:
         noise = as_device_f32(noise_profile)
-        noise_mag = magnitude(stft(noise if noise.dim() > 1 else noise[None], **kw))
-        if noise_mag.shape[0] not in (1, rows):
-            raise ValueError(f"noise_profile has {noise_mag.shape[0]} rows, the audio {rows}")
-        thr = ops.noise_threshold(noise_mag, None, n_std_thresh)
+        noise_spec = stft(noise if noise.dim() > 1 else noise[None], **kw)
+        if noise_spec.shape[0] not in (1, rows):
+            raise ValueError(f"noise_profile has {noise_spec.shape[0]} rows, the audio {rows}")
+        noise_rows = noise_spec.transpose(1, 2)
+        # (the threshold straight from the noise spectrum's rows: the same bits as from its magnitude plane)
+        thr = (ops.noise_threshold_spec(noise_rows, None, n_std_thresh) if noise_rows.is_contiguous()
+               else ops.noise_threshold(magnitude(noise_spec), None, n_std_thresh))
     elif stationary:
         n_quiet = max(1, int(0.1 * frames))
         if energy is None:
